@@ -1,0 +1,182 @@
+/*
+ * mfcc_hip.h -- C ABI of the MI355X-native MFCC hot path (libmfcc_hip.so).
+ *
+ * Drop-in boundary for the per-frame MFCC math of lambdaconcept/mfcc's `mfcc/core`
+ * (pre-emphasis -> framing -> Hamming -> FFT -> |.|^2 -> mel -> log2 -> DCT-II -> keep n_cep).
+ * The reference has no software operator API for this path: it sits behind
+ *   (1) the RTL stream interface  MFCC.sink / MFCC.source / MFCC.reset   mfcc/core/mfcc.py:28-30
+ *   (2) the host driver's C calls  mfcc_open / mfcc_convert / mfcc_close  software/main.c:36,100,53
+ *       over the transport           ft601_write / ft601_read             software/ft601.h:55-56
+ * This header is the batch equivalent of (2): one call = whole utterance(s) instead of a
+ * USB ping-pong per frame.  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * Conventions kept from the reference:
+ *   - 0 = success, negative error codes in the ft601_error range      software/ft601.h:25-32
+ *   - caller owns every in/out buffer; the handle owns device tables/streams   main.c:109,40
+ *   - output layout [frame][n_cep] row-major, i.e. the `.mfcc` file layout     main.c:162-165
+ *   - nothing is printed by the library (the reference printf's; a log hook exists there,
+ *     ft601.h:43-51 -- here errors are returned and described by mfcc_hip_strerror)
+ *   - a handle is not thread-safe; distinct handles are independent            ft601.c:185,197
+ *
+ * Two numeric contracts:
+ *   float : notebook/MFCC.ipynb (float64 NumPy) evaluated in fp32 on the GPU, <= 1e-4 rel-err
+ *   fixed : the nMigen RTL arithmetic of mfcc/core + mfcc/misc/fft.py, bit-exact int16
+ */
+#ifndef MFCC_HIP_H
+#define MFCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFCC_HIP_ABI_VERSION 1
+
+/* error codes: same numbering family as `enum ft601_error` (software/ft601.h:25-32) */
+enum mfcc_hip_error {
+    MFCC_HIP_SUCCESS             = 0,
+    MFCC_HIP_ERROR_INVALID_PARAM = -101,
+    MFCC_HIP_ERROR_NOT_FOUND     = -102,   /* no usable HIP device                     */
+    MFCC_HIP_ERROR_NO_MEM        = -103,
+    MFCC_HIP_ERROR_BUSY          = -104,
+    MFCC_HIP_ERROR_UNSUPPORTED   = -105,   /* parameter combination has no kernel      */
+    MFCC_HIP_ERROR_BUFFER_SMALL  = -106,   /* caller's output capacity is too small    */
+    MFCC_HIP_ERROR_IO            = -107,   /* file open/read/write (wav -> .mfcc)      */
+    MFCC_HIP_ERROR_OTHER         = -200    /* HIP runtime error, see mfcc_hip_last_hip_error */
+};
+
+/* framing of the tail of a stream */
+enum mfcc_hip_pad_mode {
+    /* notebook/MFCC.ipynb cell 9: frames = int((n - nfft) / hop) + 1, tail samples dropped */
+    MFCC_HIP_PAD_NOTEBOOK = 0,
+    /* host driver + RTL bench: zeros are fed after EOF until the frame holding the last
+     * sample is out: frames = (n - nfft) / hop + 2 (1 if n < nfft)   software/main.c:95,134-144 */
+    MFCC_HIP_PAD_STREAM = 1
+};
+
+/* which float kernel to run (the results agree to fp32 rounding) */
+enum mfcc_hip_float_impl {
+    MFCC_HIP_IMPL_AUTO = 0,     /* fastest kernel that supports the parameters          */
+    MFCC_HIP_IMPL_GENERIC = 1,  /* one frame per wave, any supported nfft / n_mel       */
+    MFCC_HIP_IMPL_FUSED512 = 2  /* 512/170/32 specialised kernel                        */
+};
+
+/*
+ * Parameters = the constructor arguments of `MFCC(width=16, nfft, samplerate, nfilters,
+ * nceptrums)` (mfcc/core/mfcc.py:20-21) plus the host driver's constants
+ * (`NFFT 512, STEPSIZE 170, NCEPSTRUMS, SAMPLERATE 16000`, software/main.c:11-14).
+ */
+typedef struct mfcc_hip_params {
+    uint32_t struct_size;  /* = sizeof(mfcc_hip_params); set by mfcc_hip_default_params   */
+    int32_t  nfft;         /* 512.  float: 256/512/1024; fixed: power of two 64..1024     */
+    int32_t  hop;          /* 170.  0 -> nfft / 3 (mfcc/core/mfcc.py:43)                  */
+    int32_t  n_mel;        /* 32.   float: 1..64; fixed: 4*n_mel must be a power of two   */
+    int32_t  n_cep;        /* 13.   1..n_mel; `Discard(first=0, count)` misc/discard.py   */
+    int32_t  sample_rate;  /* 16000                                                       */
+    int32_t  pad_mode;     /* enum mfcc_hip_pad_mode                                      */
+    float    power_scale;  /* float path: P = |X / power_scale|^2.  The notebook hard-codes
+                              512 (cell 22); 0 -> nfft                                    */
+    float    lifter;       /* float path: sinusoidal lifter L (MFCC.ipynb cell 43,
+                              software/lift.py:12); 0 = off                               */
+    int32_t  device;       /* HIP device ordinal; -1 = the current device                 */
+    int32_t  float_impl;   /* enum mfcc_hip_float_impl                                    */
+    int32_t  reserved[5];  /* must be zero                                                */
+} mfcc_hip_params;
+
+typedef struct mfcc_hip_handle mfcc_hip_handle;
+
+/* ---- lifetime: replaces mfcc_open / mfcc_close (software/main.c:36-56) ------------- */
+
+int  mfcc_hip_abi_version(void);
+/* fills *p with nfft 512, hop 170, n_mel 32, n_cep 13, 16 kHz, NOTEBOOK, scale 512 */
+int  mfcc_hip_default_params(mfcc_hip_params *p);
+/* validates, builds the constant tables on the host, uploads them, creates a stream.
+ * Fails with MFCC_HIP_ERROR_NOT_FOUND when no GPU is present: there is no CPU fallback. */
+int  mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out);
+void mfcc_hip_destroy(mfcc_hip_handle *h);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the
+ * handle's own stream */
+int  mfcc_hip_set_stream(mfcc_hip_handle *h, void *hip_stream);
+int  mfcc_hip_synchronize(mfcc_hip_handle *h);
+
+/* ---- host-only helpers (work without a GPU) ------------------------------------------ */
+
+/* frame count for a stream of n_samples under p->pad_mode (`nframes`, main.c:95) */
+int  mfcc_hip_num_frames(const mfcc_hip_params *p, size_t n_samples, size_t *n_frames);
+const char *mfcc_hip_strerror(int err);
+/* hipError_t of the last failing runtime call on this handle (0 if none) */
+int  mfcc_hip_last_hip_error(const mfcc_hip_handle *h);
+
+/* The constant tables the kernels use, as built on the host (no GPU needed) -- lets the
+ * CPU test-suite check the table builders against the oracle.  `which`: */
+enum mfcc_hip_table {
+    MFCC_HIP_TABLE_WINDOW_F32      = 0,  /* float[nfft]            periodic Hamming       */
+    MFCC_HIP_TABLE_MEL_POINTS_I32  = 1,  /* int32[n_mel + 2]       filter points          */
+    MFCC_HIP_TABLE_MEL_DENSE_F32   = 2,  /* float[n_mel][nfft/2+1] weights (unscaled)     */
+    MFCC_HIP_TABLE_DCT_F32         = 3,  /* float[n_cep][n_mel]    ortho DCT-II (x lifter)*/
+    MFCC_HIP_TABLE_FX_CURVE_I32    = 4,  /* int32[nfft]            RTL window curve       */
+    MFCC_HIP_TABLE_FX_TWIDDLE_I32  = 5,  /* int32[nfft/2][2]       RTL twiddle ROM re,im  */
+    MFCC_HIP_TABLE_FX_MEL_DENSE_U32 = 6  /* uint32[n_mel][nfft/2]  RTL filterbank weights
+                                            (x 2^-30), closed form of the accumulators    */
+};
+/* writes up to `cap_bytes`; *n_bytes = size of the table */
+int  mfcc_hip_get_table(const mfcc_hip_params *p, int which, void *buf, size_t cap_bytes,
+                        size_t *n_bytes);
+
+/* ---- the hot path: replaces the per-frame ft601_write / ft601_read loop of
+ *      mfcc_convert (software/main.c:128-166) ------------------------------------------ */
+
+/*
+ * Host buffers.  pcm: [n_channels][n_samples_per_ch] int16 (each channel is an independent
+ * stream: pre-emphasis history starts at 0, as after `mfcc_softreset`, main.c:21-34).
+ * out: [n_channels][n_frames][n_cep].  out_capacity counts elements of out.
+ * Synchronous: returns after the results are in `out`.
+ */
+int  mfcc_hip_process_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n_samples_per_ch,
+                          size_t n_channels, float *out, size_t out_capacity, size_t *n_frames);
+int  mfcc_hip_process_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n_samples_per_ch,
+                                size_t n_channels, int16_t *out, size_t out_capacity,
+                                size_t *n_frames);
+
+/*
+ * Device-resident buffers (HBM in, HBM out), asynchronous on the handle's stream.
+ * d_pcm:  channel c starts at d_pcm + c * ch_stride_samples (int16 units).
+ * halo:   0 or 1.  1 = the first sample of every channel is only pre-emphasis history
+ *         (x[-1] of a shard cut out of a longer stream); frames start at sample 1 and
+ *         n_samples_per_ch does not count it.  Used for frame-range sharding.
+ * d_out:  [n_channels][n_frames][n_cep], float (float path) or int16 (fixed path).
+ */
+int  mfcc_hip_process_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t n_samples_per_ch,
+                              size_t ch_stride_samples, size_t n_channels, int halo,
+                              void *d_out, size_t *n_frames);
+int  mfcc_hip_process_fixed_i16_dev(mfcc_hip_handle *h, const void *d_pcm,
+                                    size_t n_samples_per_ch, size_t ch_stride_samples,
+                                    size_t n_channels, int halo, void *d_out, size_t *n_frames);
+
+/*
+ * Measurement helper: `iters` back-to-back launches of the float (fixed = 0) or fixed
+ * (fixed = 1) kernel on device-resident buffers, bracketed by HIP events recorded on the
+ * stream the kernel is launched on; *avg_ms = elapsed / iters.  Used by bench.py for the
+ * `roofline.achieved` figure.
+ */
+int  mfcc_hip_time_dev(mfcc_hip_handle *h, int fixed, const void *d_pcm, size_t n_samples_per_ch,
+                       size_t ch_stride_samples, size_t n_channels, void *d_out,
+                       int warmup, int iters, float *avg_ms);
+
+/* name of the kernel symbol process_*_dev launches for this handle (to match rocprofv3 rows) */
+const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed);
+
+/* ---- file-level convenience: mfcc_convert(sess, wav_in, mfcc_out)  software/main.c:100 --- */
+
+/* 16-bit mono PCM WAV at p->sample_rate -> raw int16 LE `.mfcc` file [frame][n_cep]
+ * (fixed = 1: RTL-exact values, what the FPGA would have written; fixed = 0: float
+ * coefficients truncated to int16 like software/lift.py:39).  *n_frames_out may be NULL. */
+int  mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfcc_out,
+                          int fixed, size_t *n_frames_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFCC_HIP_H */

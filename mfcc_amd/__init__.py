@@ -1,0 +1,14 @@
+"""mfcc_amd -- MI355X-native MFCC hot path (gfx950 HIP kernels behind a C ABI).
+
+Drop-in for the per-frame math of lambdaconcept/mfcc's ``mfcc/core`` and nothing else:
+``MFCC`` mirrors the core's constructor (mfcc/core/mfcc.py:20-21), ``mfcc_open / mfcc_convert /
+mfcc_close / show_dir_content`` mirror the host driver (software/main.c).  All arithmetic runs
+in ``libmfcc_hip.so``; importing this package needs the library to be built (no CPU fallback).
+"""
+from ._lib import MfccHipError, LIB_PATH, load as load_library  # noqa: F401
+from .api import (MFCC, PAD_NOTEBOOK, PAD_STREAM, get_table, lifter, make_params, mfcc_close,  # noqa: F401
+                  mfcc_convert, mfcc_open, num_frames, show_dir_content)
+
+__all__ = ["MFCC", "mfcc_open", "mfcc_convert", "mfcc_close", "show_dir_content", "lifter",
+           "num_frames", "get_table", "make_params", "MfccHipError", "load_library",
+           "PAD_NOTEBOOK", "PAD_STREAM"]

@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's interface for the MFCC hot path.
+
+The reference exposes this path two ways and both are mirrored here, names and argument
+meaning kept:
+
+* ``MFCC(width=16, nfft=512, samplerate=16e3, nfilters=16, nceptrums=16)`` -- the nMigen core's
+  constructor, ``mfcc/core/mfcc.py:20-21`` (stream in: ``sink``, stream out: ``source``, ``reset``).
+  Here the streams become whole arrays: :meth:`MFCC.process` (float contract, fp32 on the GPU)
+  and :meth:`MFCC.process_fixed` (RTL-exact int16).
+* ``mfcc_open / mfcc_convert(sess, path_in, path_out) / mfcc_close`` -- the host driver,
+  ``software/main.c:36,100,53``, plus the directory walker ``show_dir_content`` (:206-247).
+
+Everything numerical happens in libmfcc_hip.so (HIP kernels); this module only marshals
+buffers.  Without a GPU :class:`MFCC` construction raises ``MfccHipError(NOT_FOUND)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MfccHipError, Params
+
+PAD_NOTEBOOK = _lib.PAD_NOTEBOOK
+PAD_STREAM = _lib.PAD_STREAM
+_PAD = {"notebook": PAD_NOTEBOOK, "stream": PAD_STREAM, PAD_NOTEBOOK: PAD_NOTEBOOK, PAD_STREAM: PAD_STREAM}
+_IMPL = {"auto": _lib.IMPL_AUTO, "generic": _lib.IMPL_GENERIC, "fused512": _lib.IMPL_FUSED512}
+
+
+def make_params(nfft=512, hop=None, nfilters=32, nceptrums=13, samplerate=16000, pad_mode="notebook",
+                power_scale=512.0, lifter=0.0, device=-1, impl="auto") -> Params:
+    lib = _lib.load()
+    p = Params()
+    _lib.check(lib.mfcc_hip_default_params(C.byref(p)))
+    p.nfft = int(nfft)
+    p.hop = 0 if hop is None else int(hop)          # 0 -> nfft // 3 (mfcc/core/mfcc.py:43)
+    p.n_mel = int(nfilters)
+    p.n_cep = int(nceptrums)
+    p.sample_rate = int(samplerate)
+    p.pad_mode = _PAD[pad_mode]
+    p.power_scale = float(power_scale) if power_scale else 0.0
+    p.lifter = float(lifter)
+    p.device = int(device)
+    p.float_impl = _IMPL[impl] if isinstance(impl, str) else int(impl)
+    return p
+
+
+def num_frames(n_samples, **kw) -> int:
+    """Frames a stream of ``n_samples`` yields (host-only; `nframes`, software/main.c:95)."""
+    lib = _lib.load()
+    p = make_params(**kw)
+    out = C.c_size_t(0)
+    _lib.check(lib.mfcc_hip_num_frames(C.byref(p), int(n_samples), C.byref(out)), "num_frames")
+    return int(out.value)
+
+
+_TABLE_DTYPES = {
+    _lib.TABLE_WINDOW_F32: np.float32, _lib.TABLE_MEL_POINTS_I32: np.int32,
+    _lib.TABLE_MEL_DENSE_F32: np.float32, _lib.TABLE_DCT_F32: np.float32,
+    _lib.TABLE_FX_CURVE_I32: np.int32, _lib.TABLE_FX_TWIDDLE_I32: np.int32,
+    _lib.TABLE_FX_MEL_DENSE_U32: np.uint32,
+}
+
+
+def get_table(which, **kw) -> np.ndarray:
+    """The constant tables as the library's host code builds them (works without a GPU)."""
+    lib = _lib.load()
+    p = make_params(**kw)
+    n = C.c_size_t(0)
+    _lib.check(lib.mfcc_hip_get_table(C.byref(p), which, None, 0, C.byref(n)), "get_table")
+    buf = np.empty(n.value, dtype=np.uint8)
+    _lib.check(lib.mfcc_hip_get_table(C.byref(p), which, buf.ctypes.data, buf.nbytes, C.byref(n)))
+    return buf.view(_TABLE_DTYPES[which])
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class MFCC:
+    """``MFCC(width=16, nfft=512, samplerate=16e3, nfilters=16, nceptrums=16)`` -- same
+    constructor arguments as ``mfcc/core/mfcc.py:20-21``; extra keyword arguments select the
+    host driver's framing (``pad_mode``), the float path's power scale / lifter and the device.
+
+    ``hop`` defaults to ``nfft // 3`` like the core (``mfcc.py:43``); the notebook and the host
+    driver hard-code 170 for nfft 512, which is the same number.
+    """
+
+    def __init__(self, width=16, nfft=512, samplerate=16e3, nfilters=16, nceptrums=16, *, hop=None,
+                 pad_mode="notebook", power_scale=512.0, lifter=0.0, device=-1, impl="auto"):
+        if width != 16:
+            raise ValueError("only width=16 (int16 PCM) is supported, like every reference target")
+        self.width = width
+        self.nfft = int(nfft)
+        self.samplerate = samplerate
+        self.nfilters = int(nfilters)
+        self.nceptrums = int(nceptrums)
+        self._lib = _lib.load()
+        self._params = make_params(nfft=nfft, hop=hop, nfilters=nfilters, nceptrums=nceptrums,
+                                   samplerate=int(samplerate), pad_mode=pad_mode, power_scale=power_scale,
+                                   lifter=lifter, device=device, impl=impl)
+        self.hop = self._params.hop or self.nfft // 3
+        h = C.c_void_p()
+        _lib.check(self._lib.mfcc_hip_create(C.byref(self._params), C.byref(h)), "mfcc_hip_create")
+        self._h = h
+
+    # -- lifetime (``reset`` of the core clears all state: every call here starts from reset)
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mfcc_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def num_frames(self, n_samples) -> int:
+        out = C.c_size_t(0)
+        _lib.check(self._lib.mfcc_hip_num_frames(C.byref(self._params), int(n_samples), C.byref(out)))
+        return int(out.value)
+
+    def kernel_name(self, fixed=False) -> str:
+        return self._lib.mfcc_hip_kernel_name(self._h, int(fixed)).decode()
+
+    def set_stream(self, stream_ptr):
+        """Launch on a caller-provided hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _lib.check(self._lib.mfcc_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        _lib.check(self._lib.mfcc_hip_synchronize(self._h))
+
+    # -- the hot path ---------------------------------------------------------------
+    def _host(self, pcm, fixed):
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype != np.int16:
+            raise TypeError("pcm must be int16 (the core's sink is signed 16 bit, mfcc.py:29)")
+        squeeze = pcm.ndim == 1
+        if squeeze:
+            pcm = pcm[None, :]
+        if pcm.ndim != 2:
+            raise ValueError("pcm must be (n,) or (channels, n)")
+        nch, n = pcm.shape
+        nf = self.num_frames(n)
+        out = np.empty((nch, nf, self.nceptrums), dtype=np.int16 if fixed else np.float32)
+        got = C.c_size_t(0)
+        fn = self._lib.mfcc_hip_process_fixed_i16 if fixed else self._lib.mfcc_hip_process_i16
+        _lib.check(fn(self._h, pcm.ctypes.data, n, nch, out.ctypes.data, out.size, C.byref(got)),
+                   "process")
+        assert got.value == nf
+        return out[0] if squeeze else out
+
+    def _dev(self, pcm, fixed, halo, out):
+        import torch
+        if pcm.dtype != torch.int16 or not pcm.is_cuda:
+            raise TypeError("device path needs a CUDA(HIP) int16 tensor")
+        squeeze = pcm.dim() == 1
+        if squeeze:
+            pcm = pcm[None, :]
+        if pcm.stride(1) != 1:
+            pcm = pcm.contiguous()
+        nch, n_tot = pcm.shape
+        n = n_tot - int(halo)
+        nf = self.num_frames(n)
+        if out is None:
+            out = torch.empty((nch, nf, self.nceptrums), device=pcm.device,
+                              dtype=torch.int16 if fixed else torch.float32)
+        self.set_stream(torch.cuda.current_stream(pcm.device).cuda_stream)
+        fn = self._lib.mfcc_hip_process_fixed_i16_dev if fixed else self._lib.mfcc_hip_process_i16_dev
+        got = C.c_size_t(0)
+        _lib.check(fn(self._h, C.c_void_p(pcm.data_ptr()), n, pcm.stride(0), nch, int(halo),
+                      C.c_void_p(out.data_ptr()), C.byref(got)), "process_dev")
+        return out[0] if squeeze else out
+
+    def process(self, pcm, halo=0, out=None):
+        """Float contract: int16 PCM ``(n,)`` / ``(channels, n)`` -> float32 ``(.., frames, nceptrums)``.
+        NumPy in -> NumPy out (H2D, kernel, D2H); torch CUDA tensor in -> torch tensor out, asynchronous
+        on the current stream.  ``halo=1`` (device path): sample 0 of every channel is history only."""
+        if _is_torch(pcm):
+            return self._dev(pcm, False, halo, out)
+        if halo:
+            raise ValueError("halo is only available on the device path")
+        return self._host(pcm, False)
+
+    def process_fixed(self, pcm, halo=0, out=None):
+        """Fixed contract (RTL arithmetic): int16 PCM -> int16 coefficients, bit-exact."""
+        if _is_torch(pcm):
+            return self._dev(pcm, True, halo, out)
+        if halo:
+            raise ValueError("halo is only available on the device path")
+        return self._host(pcm, True)
+
+    def time_launches(self, pcm, out, fixed=False, warmup=2, iters=10) -> float:
+        """Average kernel time in ms over ``iters`` launches, HIP events on the launch stream."""
+        import torch
+        if pcm.dim() == 1:
+            pcm = pcm[None, :]
+        self.set_stream(torch.cuda.current_stream(pcm.device).cuda_stream)
+        ms = C.c_float(0)
+        _lib.check(self._lib.mfcc_hip_time_dev(self._h, int(fixed), C.c_void_p(pcm.data_ptr()), pcm.shape[1],
+                                               pcm.stride(0), pcm.shape[0], C.c_void_p(out.data_ptr()),
+                                               warmup, iters, C.byref(ms)), "time_dev")
+        return float(ms.value)
+
+    # -- file level: mfcc_convert(sess, path_in, path_out), software/main.c:100-177 -----
+    def convert(self, path_in, path_out, fixed=True) -> int:
+        """``x.wav -> x.mfcc``: raw int16 LE ``[frame][nceptrums]``.  Returns the frame count."""
+        nf = C.c_size_t(0)
+        _lib.check(self._lib.mfcc_hip_convert_wav(self._h, os.fsencode(path_in), os.fsencode(path_out),
+                                                  int(fixed), C.byref(nf)), "convert %s" % path_in)
+        return int(nf.value)
+
+
+# ---- software/main.c names ---------------------------------------------------------------
+
+def mfcc_open(**kw) -> MFCC:
+    """``mfcc_open`` (main.c:36): a session with the host driver's constants
+    ``NFFT 512, STEPSIZE 170, NCEPSTRUMS 32, SAMPLERATE 16000`` (main.c:11-14) and its
+    zero-padded tail frame (main.c:134-144)."""
+    args = dict(nfft=512, samplerate=16000, nfilters=32, nceptrums=32, pad_mode="stream")
+    args.update(kw)
+    return MFCC(**args)
+
+
+def mfcc_convert(sess: MFCC, path_in, path_out, fixed=True) -> int:
+    """``mfcc_convert(sess, path_in, path_out)`` (main.c:100); 0 on success like the original."""
+    sess.convert(path_in, path_out, fixed=fixed)
+    return 0
+
+
+def mfcc_close(sess: MFCC) -> None:
+    sess.close()
+
+
+def show_dir_content(sess: MFCC, path, fixed=True):
+    """Recursive ``*.wav -> *.mfcc`` walk of ``show_dir_content`` (main.c:206-247).
+    Returns the list of (wav, mfcc) pairs converted."""
+    done = []
+    for root, _dirs, files in os.walk(path):
+        for name in sorted(files):
+            if name.endswith(".wav"):
+                src = os.path.join(root, name)
+                dst = src[:-3] + "mfcc"
+                mfcc_convert(sess, src, dst, fixed=fixed)
+                done.append((src, dst))
+    return done
+
+
+def lifter(cepstra, L=22):
+    """``lifter(cepstra, L=22)`` of software/lift.py:12-26 on a ``.mfcc`` array (host-side post
+    step on files; the float kernel can fold the same lifter in via ``MFCC(lifter=L)``)."""
+    cepstra = np.asarray(cepstra)
+    if L > 0:
+        n = np.arange(cepstra.shape[1])
+        return (1 + (L / 2.) * np.sin(np.pi * n / L)) * cepstra
+    return cepstra

@@ -1,0 +1,302 @@
+// Generic (correctness-first) gfx950 kernels: one frame per 64-lane wave, four waves per
+// workgroup, the frame staged in LDS.
+//
+//   mfcc_float_generic_kernel<NFFT> : float contract (notebook/MFCC.ipynb), any n_mel <= 64
+//   mfcc_fixed_kernel               : fixed contract (the RTL arithmetic), bit-exact int16
+//
+// The specialised 512/170/32 kernel lives in kernel_fused512.hpp; these are the reference
+// implementations on the device and the fallback for other parameter sets.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mfcc_k {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kMaxMel = 64;
+
+struct StreamDesc {
+    const int16_t *pcm;        // first frame sample of channel 0 (after the halo sample, if any)
+    long long ch_stride;       // samples between channels
+    long long n_samples;       // valid samples per channel (x[i] = 0 for i >= n_samples)
+    int halo;                  // 1: pcm[-1] is real history; 0: history is 0
+    long long frames_per_ch;
+    long long total_frames;    // frames_per_ch * n_channels
+    int hop;
+};
+
+__device__ __forceinline__ float sample_at(const StreamDesc &s, const int16_t *base, long long i) {
+    // x[i] of one channel: 0 beyond the end (stream padding), history before the start
+    if (i >= s.n_samples) return 0.0f;
+    if (i < 0) return s.halo ? float(base[-1]) : 0.0f;
+    return float(base[i]);
+}
+
+__device__ __forceinline__ int sample_at_i(const StreamDesc &s, const int16_t *base, long long i) {
+    if (i >= s.n_samples) return 0;
+    if (i < 0) return s.halo ? int(base[-1]) : 0;
+    return int(base[i]);
+}
+
+// ------------------------------------------------------------------------------ float
+
+struct FloatTables {
+    const float  *window;     // [NFFT]
+    const float2 *tw_fft;     // [NFFT/2]     W_M^m, M = NFFT/2 (complex FFT length)
+    const float2 *tw_split;   // [NFFT/2 + 1] W_NFFT^k
+    const int    *mel_start;  // [n_mel]
+    const int    *mel_count;  // [n_mel]
+    const int    *mel_off;    // [n_mel] offset into mel_w
+    const float  *mel_w;      // packed weights, 1/power_scale^2 folded in
+    const float  *dct;        // [n_cep][n_mel] (lifter folded in)
+    int n_mel, n_cep;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One workgroup = 4 waves, each wave owns one frame per iteration.
+// LDS per wave: two ping-pong buffers of M complex (Stockham), later reused for power/mel.
+template <int NFFT>
+__global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s, FloatTables t,
+                                                                  float *__restrict__ out) {
+    constexpr int M = NFFT / 2;                 // complex FFT length (real-FFT packing)
+    __shared__ float2 bufA[kWavesPerBlock][M];
+    __shared__ float2 bufB[kWavesPerBlock][M + 1];
+    __shared__ float  melv[kWavesPerBlock][kMaxMel];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long waves_total = (long long)gridDim.x * kWavesPerBlock;
+    const long long iters = (s.total_frames + waves_total - 1) / waves_total;
+
+    for (long long it = 0; it < iters; ++it) {
+        const long long fid = it * waves_total + (long long)blockIdx.x * kWavesPerBlock + wave;
+        const bool valid = fid < s.total_frames;
+        const long long ch = valid ? fid / s.frames_per_ch : 0;
+        const long long f = valid ? fid % s.frames_per_ch : 0;
+        const int16_t *base = s.pcm + ch * s.ch_stride;
+        const long long n0 = f * (long long)s.hop;
+
+        // pre-emphasis (MFCC.ipynb cell 7) + Hamming (cell 18); z[m] = y[2m] + i y[2m+1]
+        float *za = reinterpret_cast<float *>(bufA[wave]);
+        for (int i = lane; i < NFFT; i += 64) {
+            float x0 = valid ? sample_at(s, base, n0 + i) : 0.0f;
+            float x1 = valid ? sample_at(s, base, n0 + i - 1) : 0.0f;
+            // y[0] = x[0] for the very first sample of a stream: history is 0 there
+            float y = x0 - 0.96875f * x1;
+            za[i] = y * t.window[i];
+        }
+        __syncthreads();
+
+        // Stockham autosort FFT of length M: radix-4 passes, one radix-2 pass if needed
+        float2 *src = bufA[wave];
+        float2 *dst = bufB[wave];
+        int Ns = 1;
+        for (; Ns * 4 <= M; Ns *= 4) {
+            const int tstride = M / (Ns * 4);
+            for (int j = lane; j < M / 4; j += 64) {
+                const int k = j & (Ns - 1);
+                float2 v0 = src[j];
+                float2 v1 = cmul(src[j + M / 4], t.tw_fft[k * tstride]);
+                float2 v2 = cmul(src[j + 2 * (M / 4)], t.tw_fft[2 * k * tstride]);
+                float2 v3 = cmul(src[j + 3 * (M / 4)], t.tw_fft[3 * k * tstride]);
+                float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+                float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+                float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);      // -i * (v1 - v3)
+                const int j0 = ((j - k) << 2) + k;
+                dst[j0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+                dst[j0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+                dst[j0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+                dst[j0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+        }
+        if (Ns < M) {                       // remaining radix-2 pass (M = 2 * 4^n)
+            const int tstride = M / (Ns * 2);
+            for (int j = lane; j < M / 2; j += 64) {
+                const int k = j & (Ns - 1);
+                float2 v0 = src[j];
+                float2 v1 = cmul(src[j + M / 2], t.tw_fft[k * tstride]);
+                const int j0 = ((j - k) << 1) + k;
+                dst[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                dst[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+        }
+
+        // real-FFT split + power spectrum (cells 20, 22): P[k], k = 0..M, into dst (as floats)
+        float *P = reinterpret_cast<float *>(dst);
+        for (int k = lane; k <= M; k += 64) {
+            float2 a = src[k & (M - 1)];
+            float2 b = src[(M - k) & (M - 1)];
+            float er = 0.5f * (a.x + b.x), ei = 0.5f * (a.y - b.y);      // E = (a + conj b)/2
+            float dr = a.x - b.x, di = a.y + b.y;                         // a - conj b
+            float orr = 0.5f * di, oi = -0.5f * dr;                       // O = -i/2 (a - conj b)
+            float2 w = t.tw_split[k];
+            float xr = er + (w.x * orr - w.y * oi);
+            float xi = ei + (w.x * oi + w.y * orr);
+            P[k] = xr * xr + xi * xi;
+        }
+        __syncthreads();
+
+        // mel filterbank (cells 30, 36) + log2
+        if (lane < t.n_mel) {
+            const int st = t.mel_start[lane], cnt = t.mel_count[lane];
+            const float *w = t.mel_w + t.mel_off[lane];
+            float acc = 0.0f;
+            for (int j = 0; j < cnt; ++j) acc = fmaf(P[st + j], w[j], acc);
+            melv[wave][lane] = log2f(acc);
+        }
+        __syncthreads();
+
+        // DCT-II, first n_cep rows (cells 38-39)
+        if (valid && lane < t.n_cep) {
+            const float *d = t.dct + lane * t.n_mel;
+            float acc = 0.0f;
+            for (int n = 0; n < t.n_mel; ++n) acc = fmaf(d[n], melv[wave][n], acc);
+            out[fid * t.n_cep + lane] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------ fixed
+
+struct FixedTables {
+    const int   *curve;       // [nfft]     window curve (mfcc/core/window.py)
+    const int2  *tw_fft;      // [nfft/2]   Q14 twiddles of the nfft-point FFT
+    const int2  *tw_dct;      // [2*n_mel]  Q14 twiddles of the (4*n_mel)-point FFT
+    const int   *mel_start;   // [n_mel]
+    const int   *mel_count;   // [n_mel]
+    const int   *mel_off;     // [n_mel]
+    const uint32_t *mel_w;    // packed weights (x 2^-30)
+    int mel_shift;
+    int nfft, log2_nfft, n_mel, log2_dct, n_cep;
+};
+
+__device__ __forceinline__ int wrap16(int v) { return (int)(short)(v & 0xFFFF); }
+
+// mfcc/misc/fft.py:140-192 butterfly, bias 8191, >>14, then the per-stage >>1
+__device__ __forceinline__ void fx_butterfly(int2 x0, int2 x1, int2 tw, int2 &y0, int2 &y1) {
+    int m0 = (x1.x + x1.y) * tw.x + 8191;
+    int a1 = (m0 - x1.y * (tw.x + tw.y)) >> 14;
+    int a2 = (m0 - x1.x * (tw.x - tw.y)) >> 14;
+    y0 = make_int2(wrap16((x0.x + a1) >> 1), wrap16((x0.y + a2) >> 1));
+    y1 = make_int2(wrap16((x0.x - a1) >> 1), wrap16((x0.y - a2) >> 1));
+}
+
+// in-place radix-2 DIT over `size` points held in LDS (bit-reversed input order);
+// schedule of mfcc/misc/fft.py:216-344 (see oracle/mfcc_fixed.py: fft_fixed)
+__device__ __forceinline__ void fx_fft_inplace(int2 *x, int size, int L, const int2 *tw, int lane) {
+    const int half = size >> 1;
+    for (int st = 0; st < L; ++st) {
+        for (int tp = lane; tp < half; tp += 64) {
+            const int j = tp & ((1 << st) - 1);
+            const int i0 = ((tp >> st) << (st + 1)) | j;
+            const int i1 = i0 + (1 << st);
+            const int ta = (j << (L - 1 - st)) & (half - 1);
+            int2 y0, y1;
+            fx_butterfly(x[i0], x[i1], tw[ta], y0, y1);
+            x[i0] = y0;
+            x[i1] = y1;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kFxMaxNfft = 1024;
+
+__global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedTables t,
+                                                          int16_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // per wave: int2 x[nfft]; uint32 P[nfft/2] aliases nothing (separate); int mel[64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nfft = t.nfft;
+    int2 *x = reinterpret_cast<int2 *>(smem) + (size_t)wave * nfft;
+    uint32_t *P = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(int2)) +
+                  (size_t)wave * (nfft / 2);
+    int *melv = reinterpret_cast<int *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(int2) +
+                                        (size_t)kWavesPerBlock * (nfft / 2) * sizeof(uint32_t)) +
+                wave * kMaxMel;
+
+    const long long waves_total = (long long)gridDim.x * kWavesPerBlock;
+    const long long iters = (s.total_frames + waves_total - 1) / waves_total;
+    const int L = t.log2_nfft;
+
+    for (long long it = 0; it < iters; ++it) {
+        const long long fid = it * waves_total + (long long)blockIdx.x * kWavesPerBlock + wave;
+        const bool valid = fid < s.total_frames;
+        const long long ch = valid ? fid / s.frames_per_ch : 0;
+        const long long f = valid ? fid % s.frames_per_ch : 0;
+        const int16_t *base = s.pcm + ch * s.ch_stride;
+        const long long n0 = f * (long long)s.hop;
+
+        // preemph.py:24  y = wrap16(x + (o >> 5) - o);  window.py:84  (y * curve) >> 9;
+        // fft.py:413-424 bit-reversed load, imag = 0
+        for (int i = lane; i < nfft; i += 64) {
+            int x0 = valid ? sample_at_i(s, base, n0 + i) : 0;
+            int o = valid ? sample_at_i(s, base, n0 + i - 1) : 0;
+            int y = wrap16(x0 + (o >> 5) - o);
+            int w = (y * t.curve[i]) >> 9;
+            int r = (int)(__brev((unsigned)i) >> (32 - L));
+            x[r] = make_int2(w, 0);
+        }
+        __syncthreads();
+        fx_fft_inplace(x, nfft, L, t.tw_fft, lane);
+
+        // pow2.py:32,64  (re^2 + im^2) >> 2, 30 bits
+        for (int k = lane; k < nfft / 2; k += 64) {
+            int2 v = x[k];
+            uint32_t r = (uint32_t)(v.x * v.x) + (uint32_t)(v.y * v.y);
+            P[k] = r >> 2;
+        }
+        __syncthreads();
+
+        // filterbank.py:88-142 in closed form (tables.hpp: fx_mel), then log.py Log2Fix(16, 15)
+        if (lane < t.n_mel) {
+            const int st = t.mel_start[lane], cnt = t.mel_count[lane];
+            const uint32_t *w = t.mel_w + t.mel_off[lane];
+            unsigned long long acc = 0;
+            for (int j = 0; j < cnt; ++j) acc += (unsigned long long)P[st + j] * (unsigned long long)w[j];
+            unsigned v = (unsigned)(acc >> t.mel_shift) & 0xFFFFu;
+            // Turner log2, Q4.11: precision 11, 10 squarings (log.py:33-102)
+            unsigned xx = (v ? v : 1u) << 11;
+            unsigned o = 0;
+            while (xx >= (1u << 12)) { xx >>= 1; o += 1u << 11; }
+            unsigned z = xx, b = 1u << 10;
+            for (int c = 0; c < 10; ++c) {
+                unsigned cc = z * z;
+                if (cc & (1u << 23)) { z = cc >> 12; o += b; } else { z = cc >> 11; }
+                b >>= 1;
+            }
+            melv[lane] = (int)(o & 0x7FFFu);
+        }
+        __syncthreads();
+
+        // dct_stream.py:23-33: y[2n+1] = y[size-1-2n] = x[n], zeros elsewhere; FFT(4*n_mel)
+        const int dsz = 4 * t.n_mel;
+        for (int i = lane; i < dsz; i += 64) {
+            int v = 0;
+            if (i & 1) {
+                int n = (i < 2 * t.n_mel) ? (i >> 1) : ((dsz - 1 - i) >> 1);
+                v = melv[n];
+            }
+            int r = (int)(__brev((unsigned)i) >> (32 - t.log2_dct));
+            x[r] = make_int2(v, 0);
+        }
+        __syncthreads();
+        fx_fft_inplace(x, dsz, t.log2_dct, t.tw_dct, lane);
+        if (valid && lane < t.n_cep) out[fid * t.n_cep + lane] = (int16_t)x[lane].x;
+        __syncthreads();
+    }
+}
+
+}  // namespace mfcc_k

@@ -1,0 +1,632 @@
+// libmfcc_hip.so -- C ABI (include/mfcc_hip.h) over the gfx950 MFCC kernels.
+//
+// Host side: parameter validation, table building (tables.hpp), device buffers, launches.
+// There is NO CPU compute path in this library: without a HIP device mfcc_hip_create fails
+// with MFCC_HIP_ERROR_NOT_FOUND (the host-only helpers -- frame counts, table dumps, error
+// strings -- keep working so the CPU test-suite can check the host logic).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mfcc_hip.h"
+#include "kernels_generic.hpp"
+#include "kernel_fused512.hpp"
+#include "tables.hpp"
+
+namespace {
+
+using namespace mfcc_tables;
+
+struct Resolved {
+    int nfft, hop, n_mel, n_cep, sample_rate, pad_mode;
+    double power_scale, lifter;
+    int device, float_impl;
+};
+
+int resolve(const mfcc_hip_params *p, Resolved &r) {
+    if (!p) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (p->struct_size != sizeof(mfcc_hip_params)) return MFCC_HIP_ERROR_INVALID_PARAM;
+    for (int v : p->reserved)
+        if (v != 0) return MFCC_HIP_ERROR_INVALID_PARAM;
+    r.nfft = p->nfft;
+    r.hop = p->hop == 0 ? p->nfft / 3 : p->hop;
+    r.n_mel = p->n_mel;
+    r.n_cep = p->n_cep;
+    r.sample_rate = p->sample_rate;
+    r.pad_mode = p->pad_mode;
+    r.power_scale = p->power_scale == 0.0f ? double(p->nfft) : double(p->power_scale);
+    r.lifter = double(p->lifter);
+    r.device = p->device;
+    r.float_impl = p->float_impl;
+    if (!is_pow2(r.nfft) || r.nfft < 64 || r.nfft > 1024) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.hop < 1 || r.hop > r.nfft) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.n_mel < 1 || r.n_mel > mfcc_k::kMaxMel) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.n_cep < 1 || r.n_cep > r.n_mel) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.sample_rate < 1) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.pad_mode != MFCC_HIP_PAD_NOTEBOOK && r.pad_mode != MFCC_HIP_PAD_STREAM)
+        return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (!(r.power_scale > 0.0) || r.lifter < 0.0) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (r.float_impl < MFCC_HIP_IMPL_AUTO || r.float_impl > MFCC_HIP_IMPL_FUSED512)
+        return MFCC_HIP_ERROR_INVALID_PARAM;
+    return MFCC_HIP_SUCCESS;
+}
+
+size_t count_frames(const Resolved &r, size_t n) {
+    if (r.pad_mode == MFCC_HIP_PAD_NOTEBOOK) {
+        if (n < size_t(r.nfft)) return 0;
+        return (n - size_t(r.nfft)) / size_t(r.hop) + 1;
+    }
+    if (n < size_t(r.nfft)) return 1;
+    return (n - size_t(r.nfft)) / size_t(r.hop) + 2;
+}
+
+bool fixed_supported(const Resolved &r) {
+    // RTL constraints: FFT sizes are powers of two (mfcc/misc/fft.py:351-353) for both the
+    // nfft-point FFT and the (4 * nfilters)-point DCT FFT; hop = nfft // 3 (mfcc/core/mfcc.py:43)
+    return is_pow2(4 * r.n_mel) && 4 * r.n_mel <= r.nfft && r.n_mel >= 4 && r.hop == r.nfft / 3 &&
+           r.nfft >= 64;
+}
+
+struct SparseRows {
+    std::vector<int> start, count, off;
+};
+
+template <typename T>
+SparseRows pack_rows(const std::vector<T> &dense, int rows, int cols, std::vector<T> &packed) {
+    SparseRows s;
+    packed.clear();
+    for (int r = 0; r < rows; ++r) {
+        int lo = cols, hi = -1;
+        for (int k = 0; k < cols; ++k)
+            if (dense[size_t(r) * cols + k] != T(0)) {
+                if (k < lo) lo = k;
+                hi = k;
+            }
+        int cnt = hi >= lo ? hi - lo + 1 : 0;
+        s.start.push_back(cnt ? lo : 0);
+        s.count.push_back(cnt);
+        s.off.push_back(int(packed.size()));
+        for (int k = 0; k < cnt; ++k) packed.push_back(dense[size_t(r) * cols + lo + k]);
+    }
+    return s;
+}
+
+}  // namespace
+
+struct mfcc_hip_handle {
+    Resolved r;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    int n_cu = 0;
+    bool fixed_ok = false;
+    bool fused_ok = false;
+    // device tables (one arena)
+    void *arena = nullptr;
+    mfcc_k::FloatTables ft{};
+    mfcc_k::FixedTables xt{};
+    mfcc_fused::FusedTables fu{};
+    // scratch for the host-buffer entry points
+    void *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    void *d_out = nullptr;
+    size_t d_out_bytes = 0;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                         \
+    do {                                         \
+        hipError_t e__ = (expr);                 \
+        if (e__ != hipSuccess) {                 \
+            (h)->last_hip = int(e__);            \
+            return e__ == hipErrorOutOfMemory ? MFCC_HIP_ERROR_NO_MEM : MFCC_HIP_ERROR_OTHER; \
+        }                                        \
+    } while (0)
+
+struct Arena {
+    std::vector<char> host;
+    template <typename T>
+    size_t put(const std::vector<T> &v) {
+        size_t off = (host.size() + 255) & ~size_t(255);
+        host.resize(off + v.size() * sizeof(T));
+        if (!v.empty()) std::memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+
+int build_tables(mfcc_hip_handle *h) {
+    const Resolved &r = h->r;
+    Arena a;
+    // ---- float
+    std::vector<double> wd = hamming_periodic(r.nfft);
+    std::vector<float> win(wd.begin(), wd.end());
+    const int M = r.nfft / 2;
+    std::vector<float2> twf(M), tws(M + 1);
+    for (int m = 0; m < M; ++m) {
+        double ang = -2.0 * kPi * double(m) / double(M);
+        twf[m] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+    }
+    for (int k = 0; k <= M; ++k) {
+        double ang = -2.0 * kPi * double(k) / double(r.nfft);
+        tws[k] = make_float2(float(std::cos(ang)), float(std::sin(ang)));
+    }
+    std::vector<double> md = mel_dense(r.nfft, r.n_mel, double(r.sample_rate));
+    const double inv_s2 = 1.0 / (r.power_scale * r.power_scale);
+    std::vector<float> mdf(md.size());
+    for (size_t i = 0; i < md.size(); ++i) mdf[i] = float(md[i] * inv_s2);
+    std::vector<float> melw;
+    SparseRows ms = pack_rows(mdf, r.n_mel, M + 1, melw);
+    if (melw.empty()) melw.push_back(0.0f);
+    std::vector<double> dd = dct_rows(r.n_cep, r.n_mel, r.lifter);
+    std::vector<float> dct(dd.begin(), dd.end());
+
+    size_t o_win = a.put(win), o_twf = a.put(twf), o_tws = a.put(tws);
+    size_t o_ms = a.put(ms.start), o_mc = a.put(ms.count), o_mo = a.put(ms.off);
+    size_t o_mw = a.put(melw), o_dct = a.put(dct);
+
+    // ---- fixed
+    size_t o_cv = 0, o_xt = 0, o_xd = 0, o_xs = 0, o_xc = 0, o_xo = 0, o_xw = 0;
+    FxMel fm;
+    h->fixed_ok = fixed_supported(r);
+    if (h->fixed_ok) {
+        std::vector<int> cv = fx_window_curve(r.nfft);
+        std::vector<int> re, im;
+        fx_twiddles(r.nfft, re, im);
+        std::vector<int2> t1(re.size());
+        for (size_t i = 0; i < re.size(); ++i) t1[i] = make_int2(re[i], im[i]);
+        fx_twiddles(4 * r.n_mel, re, im);
+        std::vector<int2> t2(re.size());
+        for (size_t i = 0; i < re.size(); ++i) t2[i] = make_int2(re[i], im[i]);
+        fm = fx_mel(r.nfft, r.n_mel, double(r.sample_rate));
+        std::vector<uint32_t> xw;
+        SparseRows xs = pack_rows(fm.dense, r.n_mel, r.nfft / 2, xw);
+        if (xw.empty()) xw.push_back(0u);
+        o_cv = a.put(cv); o_xt = a.put(t1); o_xd = a.put(t2);
+        o_xs = a.put(xs.start); o_xc = a.put(xs.count); o_xo = a.put(xs.off); o_xw = a.put(xw);
+    }
+
+    // ---- fused 512/170/32 kernel tables
+    std::vector<char> fused_blob;
+    h->fused_ok = mfcc_fused::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
+                  mfcc_fused::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+    size_t o_fu = 0;
+    if (h->fused_ok) o_fu = a.put(fused_blob);
+
+    HIP_TRY(h, hipMalloc(&h->arena, a.host.size() + 256));
+    HIP_TRY(h, hipMemcpy(h->arena, a.host.data(), a.host.size(), hipMemcpyHostToDevice));
+    char *b = static_cast<char *>(h->arena);
+    h->ft.window = reinterpret_cast<const float *>(b + o_win);
+    h->ft.tw_fft = reinterpret_cast<const float2 *>(b + o_twf);
+    h->ft.tw_split = reinterpret_cast<const float2 *>(b + o_tws);
+    h->ft.mel_start = reinterpret_cast<const int *>(b + o_ms);
+    h->ft.mel_count = reinterpret_cast<const int *>(b + o_mc);
+    h->ft.mel_off = reinterpret_cast<const int *>(b + o_mo);
+    h->ft.mel_w = reinterpret_cast<const float *>(b + o_mw);
+    h->ft.dct = reinterpret_cast<const float *>(b + o_dct);
+    h->ft.n_mel = r.n_mel;
+    h->ft.n_cep = r.n_cep;
+    if (h->fixed_ok) {
+        h->xt.curve = reinterpret_cast<const int *>(b + o_cv);
+        h->xt.tw_fft = reinterpret_cast<const int2 *>(b + o_xt);
+        h->xt.tw_dct = reinterpret_cast<const int2 *>(b + o_xd);
+        h->xt.mel_start = reinterpret_cast<const int *>(b + o_xs);
+        h->xt.mel_count = reinterpret_cast<const int *>(b + o_xc);
+        h->xt.mel_off = reinterpret_cast<const int *>(b + o_xo);
+        h->xt.mel_w = reinterpret_cast<const uint32_t *>(b + o_xw);
+        h->xt.mel_shift = fm.shift;
+        h->xt.nfft = r.nfft;
+        h->xt.log2_nfft = ilog2(r.nfft);
+        h->xt.n_mel = r.n_mel;
+        h->xt.log2_dct = ilog2(4 * r.n_mel);
+        h->xt.n_cep = r.n_cep;
+    }
+    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, h->fu);
+    return MFCC_HIP_SUCCESS;
+}
+
+bool use_fused(const mfcc_hip_handle *h) {
+    if (h->r.float_impl == MFCC_HIP_IMPL_GENERIC) return false;
+    return h->fused_ok;
+}
+
+int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t stride, size_t nch,
+           int halo, void *d_out, size_t *n_frames) {
+    if (!h || (!d_pcm && n * nch) || halo < 0 || halo > 1) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
+    if (!fixed && h->r.float_impl == MFCC_HIP_IMPL_FUSED512 && !h->fused_ok)
+        return MFCC_HIP_ERROR_UNSUPPORTED;
+    const size_t nf = count_frames(h->r, n);
+    if (n_frames) *n_frames = nf;
+    if (nf == 0 || nch == 0) return MFCC_HIP_SUCCESS;
+    if (!d_out) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (nch > 1 && stride < n + size_t(halo)) return MFCC_HIP_ERROR_INVALID_PARAM;
+
+    mfcc_k::StreamDesc s;
+    s.pcm = static_cast<const int16_t *>(d_pcm) + halo;
+    s.ch_stride = (long long)stride;
+    s.n_samples = (long long)n;
+    s.halo = halo;
+    s.frames_per_ch = (long long)nf;
+    s.total_frames = (long long)(nf * nch);
+    s.hop = h->r.hop;
+
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long total = s.total_frames;
+    if (fixed) {
+        long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
+        long long cap = (long long)h->n_cu * 8;
+        if (blocks > cap) blocks = cap;
+        size_t lds = size_t(mfcc_k::kWavesPerBlock) *
+                     (size_t(h->r.nfft) * sizeof(int2) + size_t(h->r.nfft / 2) * 4 + mfcc_k::kMaxMel * 4);
+        hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds,
+                           h->stream, s, h->xt, static_cast<int16_t *>(d_out));
+    } else if (use_fused(h)) {
+        mfcc_fused::launch(s, h->fu, static_cast<float *>(d_out), h->n_cu, h->stream);
+    } else {
+        long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
+        long long cap = (long long)h->n_cu * 8;
+        if (blocks > cap) blocks = cap;
+        float *o = static_cast<float *>(d_out);
+        switch (h->r.nfft) {
+            case 256:
+                hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<256>, dim3((unsigned)blocks),
+                                   dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
+                break;
+            case 512:
+                hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<512>, dim3((unsigned)blocks),
+                                   dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
+                break;
+            case 1024:
+                hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<1024>, dim3((unsigned)blocks),
+                                   dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
+                break;
+            default:
+                return MFCC_HIP_ERROR_UNSUPPORTED;
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MFCC_HIP_SUCCESS;
+}
+
+int ensure(mfcc_hip_handle *h, void **p, size_t *have, size_t want) {
+    if (*have >= want && *p) return MFCC_HIP_SUCCESS;
+    if (*p) {
+        HIP_TRY(h, hipFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    size_t sz = want + want / 4 + 4096;
+    HIP_TRY(h, hipMalloc(p, sz));
+    *have = sz;
+    return MFCC_HIP_SUCCESS;
+}
+
+template <typename OutT>
+int process_host(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, size_t n, size_t nch, OutT *out,
+                 size_t cap, size_t *n_frames) {
+    if (!h || (!pcm && n * nch)) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
+    const size_t nf = count_frames(h->r, n);
+    if (n_frames) *n_frames = nf;
+    if (nf == 0 || nch == 0) return MFCC_HIP_SUCCESS;
+    const size_t n_out = nf * nch * size_t(h->r.n_cep);
+    if (!out || cap < n_out) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t in_bytes = n * nch * sizeof(int16_t);
+    int rc = ensure(h, &h->d_in, &h->d_in_bytes, in_bytes + 64);
+    if (rc) return rc;
+    rc = ensure(h, &h->d_out, &h->d_out_bytes, n_out * sizeof(OutT));
+    if (rc) return rc;
+    if (in_bytes) HIP_TRY(h, hipMemcpyAsync(h->d_in, pcm, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, fixed, h->d_in, n, n, nch, 0, h->d_out, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_out, n_out * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MFCC_HIP_SUCCESS;
+}
+
+// ---- minimal RIFF/WAVE reader (the reference uses the un-vendored libwav, main.c:58-98)
+int read_wav_i16(const char *path, int want_rate, std::vector<int16_t> &pcm) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return MFCC_HIP_ERROR_IO;
+    std::vector<unsigned char> d;
+    unsigned char buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + got);
+    std::fclose(f);
+    auto u32 = [&](size_t o) { return uint32_t(d[o]) | uint32_t(d[o + 1]) << 8 | uint32_t(d[o + 2]) << 16 | uint32_t(d[o + 3]) << 24; };
+    auto u16 = [&](size_t o) { return uint16_t(d[o] | d[o + 1] << 8); };
+    if (d.size() < 12 || std::memcmp(d.data(), "RIFF", 4) || std::memcmp(d.data() + 8, "WAVE", 4))
+        return MFCC_HIP_ERROR_INVALID_PARAM;
+    size_t o = 12;
+    int fmt = 0, ch = 0, bits = 0;
+    uint32_t rate = 0;
+    bool have_fmt = false;
+    while (o + 8 <= d.size()) {
+        uint32_t sz = u32(o + 4);
+        size_t body = o + 8;
+        if (!std::memcmp(d.data() + o, "fmt ", 4) && body + 16 <= d.size()) {
+            fmt = u16(body); ch = u16(body + 2); rate = u32(body + 4); bits = u16(body + 14);
+            have_fmt = true;
+        } else if (!std::memcmp(d.data() + o, "data", 4)) {
+            // same checks as mfcc_wav_open (software/main.c:72-92): PCM, 16 bit, expected rate
+            if (!have_fmt || fmt != 1 || bits != 16 || ch != 1 || int(rate) != want_rate)
+                return MFCC_HIP_ERROR_UNSUPPORTED;
+            size_t avail = d.size() - body;
+            size_t n = (sz < avail ? sz : avail) / 2;
+            pcm.resize(n);
+            for (size_t i = 0; i < n; ++i) pcm[i] = int16_t(u16(body + 2 * i));
+            return MFCC_HIP_SUCCESS;
+        }
+        o = body + sz + (sz & 1);
+    }
+    return MFCC_HIP_ERROR_INVALID_PARAM;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+
+extern "C" {
+
+int mfcc_hip_abi_version(void) { return MFCC_HIP_ABI_VERSION; }
+
+int mfcc_hip_default_params(mfcc_hip_params *p) {
+    if (!p) return MFCC_HIP_ERROR_INVALID_PARAM;
+    std::memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->nfft = 512;             // NFFT        software/main.c:11
+    p->hop = 170;              // STEPSIZE    software/main.c:12
+    p->n_mel = 32;             // nfilters    mfcc/targets/wav2mfcc.py:19
+    p->n_cep = 13;             // BASELINE.json metric (reference tops keep 16/32)
+    p->sample_rate = 16000;    // SAMPLERATE  software/main.c:14
+    p->pad_mode = MFCC_HIP_PAD_NOTEBOOK;
+    p->power_scale = 512.0f;   // MFCC.ipynb cell 22
+    p->lifter = 0.0f;
+    p->device = -1;
+    p->float_impl = MFCC_HIP_IMPL_AUTO;
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_num_frames(const mfcc_hip_params *p, size_t n_samples, size_t *n_frames) {
+    Resolved r;
+    int rc = resolve(p, r);
+    if (rc) return rc;
+    if (!n_frames) return MFCC_HIP_ERROR_INVALID_PARAM;
+    *n_frames = count_frames(r, n_samples);
+    return MFCC_HIP_SUCCESS;
+}
+
+const char *mfcc_hip_strerror(int err) {
+    switch (err) {
+        case MFCC_HIP_SUCCESS: return "success";
+        case MFCC_HIP_ERROR_INVALID_PARAM: return "invalid parameter";
+        case MFCC_HIP_ERROR_NOT_FOUND: return "no usable HIP device (this library has no CPU path)";
+        case MFCC_HIP_ERROR_NO_MEM: return "out of memory";
+        case MFCC_HIP_ERROR_BUSY: return "busy";
+        case MFCC_HIP_ERROR_UNSUPPORTED: return "parameter combination not supported by any kernel";
+        case MFCC_HIP_ERROR_BUFFER_SMALL: return "output buffer too small";
+        case MFCC_HIP_ERROR_IO: return "file i/o error";
+        case MFCC_HIP_ERROR_OTHER: return "HIP runtime error (see mfcc_hip_last_hip_error)";
+        default: return "unknown error";
+    }
+}
+
+int mfcc_hip_last_hip_error(const mfcc_hip_handle *h) { return h ? h->last_hip : 0; }
+
+int mfcc_hip_get_table(const mfcc_hip_params *p, int which, void *buf, size_t cap, size_t *n_bytes) {
+    Resolved r;
+    int rc = resolve(p, r);
+    if (rc) return rc;
+    std::vector<char> blob;
+    auto put = [&](const void *d, size_t n) { blob.assign((const char *)d, (const char *)d + n); };
+    switch (which) {
+        case MFCC_HIP_TABLE_WINDOW_F32: {
+            std::vector<double> w = hamming_periodic(r.nfft);
+            std::vector<float> f(w.begin(), w.end());
+            put(f.data(), f.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_MEL_POINTS_I32: {
+            std::vector<int> v = mel_points(r.nfft, r.n_mel, double(r.sample_rate));
+            put(v.data(), v.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_MEL_DENSE_F32: {
+            std::vector<double> w = mel_dense(r.nfft, r.n_mel, double(r.sample_rate));
+            std::vector<float> f(w.begin(), w.end());
+            put(f.data(), f.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_DCT_F32: {
+            std::vector<double> w = dct_rows(r.n_cep, r.n_mel, r.lifter);
+            std::vector<float> f(w.begin(), w.end());
+            put(f.data(), f.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_FX_CURVE_I32: {
+            std::vector<int> v = fx_window_curve(r.nfft);
+            put(v.data(), v.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_FX_TWIDDLE_I32: {
+            std::vector<int> re, im, v;
+            fx_twiddles(r.nfft, re, im);
+            for (size_t i = 0; i < re.size(); ++i) { v.push_back(re[i]); v.push_back(im[i]); }
+            put(v.data(), v.size() * 4);
+            break;
+        }
+        case MFCC_HIP_TABLE_FX_MEL_DENSE_U32: {
+            if (!fixed_supported(r)) return MFCC_HIP_ERROR_UNSUPPORTED;
+            FxMel m = fx_mel(r.nfft, r.n_mel, double(r.sample_rate));
+            // first word: the shift; then the dense table
+            std::vector<uint32_t> v;
+            v.push_back(uint32_t(m.shift));
+            v.insert(v.end(), m.dense.begin(), m.dense.end());
+            put(v.data(), v.size() * 4);
+            break;
+        }
+        default:
+            return MFCC_HIP_ERROR_INVALID_PARAM;
+    }
+    if (n_bytes) *n_bytes = blob.size();
+    if (buf) {
+        if (cap < blob.size()) return MFCC_HIP_ERROR_BUFFER_SMALL;
+        std::memcpy(buf, blob.data(), blob.size());
+    }
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out) {
+    if (!out) return MFCC_HIP_ERROR_INVALID_PARAM;
+    *out = nullptr;
+    Resolved r;
+    int rc = resolve(p, r);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MFCC_HIP_ERROR_NOT_FOUND;
+    int dev = r.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return MFCC_HIP_ERROR_NOT_FOUND;
+    }
+    if (dev >= ndev) return MFCC_HIP_ERROR_NOT_FOUND;
+    mfcc_hip_handle *h = new (std::nothrow) mfcc_hip_handle();
+    if (!h) return MFCC_HIP_ERROR_NO_MEM;
+    h->r = r;
+    h->device = dev;
+    auto fail = [&](int code) {
+        mfcc_hip_destroy(h);
+        return code;
+    };
+    if (hipSetDevice(dev) != hipSuccess) return fail(MFCC_HIP_ERROR_NOT_FOUND);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MFCC_HIP_ERROR_OTHER);
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(MFCC_HIP_ERROR_OTHER);
+    h->stream = h->own_stream;
+    rc = build_tables(h);
+    if (rc) return fail(rc);
+    if (r.float_impl == MFCC_HIP_IMPL_FUSED512 && !h->fused_ok) return fail(MFCC_HIP_ERROR_UNSUPPORTED);
+    *out = h;
+    return MFCC_HIP_SUCCESS;
+}
+
+void mfcc_hip_destroy(mfcc_hip_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) {
+        (void)hipStreamSynchronize(h->own_stream);
+        (void)hipStreamDestroy(h->own_stream);
+    }
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_out) (void)hipFree(h->d_out);
+    delete h;
+}
+
+int mfcc_hip_set_stream(mfcc_hip_handle *h, void *hip_stream) {
+    if (!h) return MFCC_HIP_ERROR_INVALID_PARAM;
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_synchronize(mfcc_hip_handle *h) {
+    if (!h) return MFCC_HIP_ERROR_INVALID_PARAM;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_process_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n, size_t nch, float *out,
+                         size_t cap, size_t *n_frames) {
+    return process_host<float>(h, false, pcm, n, nch, out, cap, n_frames);
+}
+
+int mfcc_hip_process_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n, size_t nch,
+                               int16_t *out, size_t cap, size_t *n_frames) {
+    return process_host<int16_t>(h, true, pcm, n, nch, out, cap, n_frames);
+}
+
+int mfcc_hip_process_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t n, size_t stride, size_t nch,
+                             int halo, void *d_out, size_t *n_frames) {
+    return launch(h, false, d_pcm, n, stride, nch, halo, d_out, n_frames);
+}
+
+int mfcc_hip_process_fixed_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t n, size_t stride,
+                                   size_t nch, int halo, void *d_out, size_t *n_frames) {
+    return launch(h, true, d_pcm, n, stride, nch, halo, d_out, n_frames);
+}
+
+int mfcc_hip_time_dev(mfcc_hip_handle *h, int fixed, const void *d_pcm, size_t n, size_t stride,
+                      size_t nch, void *d_out, int warmup, int iters, float *avg_ms) {
+    if (!h || iters < 1 || warmup < 0 || !avg_ms) return MFCC_HIP_ERROR_INVALID_PARAM;
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < warmup; ++i) {
+        int rc = launch(h, fixed != 0, d_pcm, n, stride, nch, 0, d_out, nullptr);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) {
+        int rc = launch(h, fixed != 0, d_pcm, n, stride, nch, 0, d_out, nullptr);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / float(iters);
+    return MFCC_HIP_SUCCESS;
+}
+
+const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
+    if (!h) return "";
+    if (fixed) return "mfcc_fixed_kernel";
+    if (use_fused(h)) return mfcc_fused::kernel_name();
+    return "mfcc_float_generic_kernel";
+}
+
+int mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfcc_out, int fixed,
+                         size_t *n_frames_out) {
+    if (!h || !wav_in || !mfcc_out) return MFCC_HIP_ERROR_INVALID_PARAM;
+    std::vector<int16_t> pcm;
+    int rc = read_wav_i16(wav_in, h->r.sample_rate, pcm);
+    if (rc) return rc;
+    const size_t nf = count_frames(h->r, pcm.size());
+    std::vector<int16_t> cep(nf * size_t(h->r.n_cep));
+    if (fixed) {
+        rc = mfcc_hip_process_fixed_i16(h, pcm.data(), pcm.size(), 1, cep.data(), cep.size(), nullptr);
+        if (rc) return rc;
+    } else {
+        std::vector<float> f(cep.size());
+        rc = mfcc_hip_process_i16(h, pcm.data(), pcm.size(), 1, f.data(), f.size(), nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < f.size(); ++i) {
+            float v = f[i];                                   // astype(np.int16): truncate
+            if (!(v == v)) v = 0.0f;
+            if (v > 32767.0f) v = 32767.0f;
+            if (v < -32768.0f) v = -32768.0f;
+            cep[i] = int16_t(v);
+        }
+    }
+    FILE *o = std::fopen(mfcc_out, "wb");
+    if (!o) return MFCC_HIP_ERROR_IO;
+    size_t wr = cep.empty() ? 0 : std::fwrite(cep.data(), sizeof(int16_t), cep.size(), o);
+    std::fclose(o);
+    if (wr != cep.size()) return MFCC_HIP_ERROR_IO;
+    if (n_frames_out) *n_frames_out = nf;
+    return MFCC_HIP_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against the oracle
+on the same inputs.  Float contract: max|d|/max|ref| and rel-L2 <= 1e-4 (BASELINE.json).
+Fixed contract: bit-exact.  Run with `pytest -m gpu` on the MI355X box."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mfcc_fixed as mx
+from oracle import mfcc_float as mf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4        # BASELINE.json north_star: <= 1e-4 rel-err vs the float notebook
+
+
+def _err(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return (np.abs(got - ref).max() / np.abs(ref).max(),
+            np.linalg.norm(got - ref) / np.linalg.norm(ref))
+
+
+@pytest.fixture(scope="module")
+def mfcc_amd():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import mfcc_amd
+    return mfcc_amd
+
+
+IMPLS = ["generic", "auto"]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_float_golden_wav(mfcc_amd, wav_pcm, golden_dir, impl):
+    """Config 1: f2bjrop1.0.wav against the fixture made by running the reference notebook."""
+    ref = np.load(os.path.join(golden_dir, "f2bjrop_float64_cep32.npy"))[:, :13]
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl=impl) as m:
+        got = m.process(wav_pcm)
+    assert got.shape == (1046, 13) and got.dtype == np.float32
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL, (e_max, e_l2)
+    # fp32 chain should be far inside the tolerance (~1.5e-6)
+    assert e_max < 2e-5, e_max
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_float_all_32_coefficients(mfcc_amd, wav_pcm, golden_dir, impl):
+    ref = np.load(os.path.join(golden_dir, "f2bjrop_float64_cep32.npy"))
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, impl=impl) as m:
+        got = m.process(wav_pcm)
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL, (e_max, e_l2)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("n", [512, 513, 681, 682, 683, 1023, 5000, 170 * 300 + 512 + 169])
+def test_float_ragged_lengths_vs_oracle(mfcc_amd, n, impl):
+    pcm = mf.synth_pcm(n, seed=n)
+    ref = mf.mfcc_float_ref(pcm)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl=impl) as m:
+        got = m.process(pcm)
+    assert got.shape == ref.shape
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL, (n, e_max, e_l2)
+
+
+def test_float_too_short_gives_zero_frames(mfcc_amd):
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13) as m:
+        assert m.process(np.zeros(511, np.int16)).shape == (0, 13)
+        assert m.process(np.zeros((3, 100), np.int16)).shape == (3, 0, 13)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_float_stream_padding(mfcc_amd, wav_pcm, impl):
+    pcm = wav_pcm[:20000]
+    ref = mf.mfcc_float_ref(pcm, pad_mode="stream")
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode="stream", impl=impl) as m:
+        got = m.process(pcm)
+    assert got.shape == ref.shape == (mf.num_frames_stream(20000), 13)
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_float_multichannel_and_device_path(mfcc_amd, impl):
+    import torch
+    pcm = np.stack([mf.synth_pcm(30000, seed=s) for s in range(5)])
+    ref = mf.mfcc_float_ref(pcm)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl=impl) as m:
+        got = m.process(pcm)
+        dev = m.process(torch.from_numpy(pcm).cuda())
+        torch.cuda.synchronize()
+    assert got.shape == ref.shape == (5, mf.num_frames_notebook(30000), 13)
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+    assert np.array_equal(dev.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_float_halo_sharding_is_seamless(mfcc_amd, impl):
+    """Frame-range shards with a 1-sample history halo reproduce the unsharded result (8e)."""
+    import torch
+    pcm = mf.synth_pcm(170 * 400 + 512, seed=11)
+    x = torch.from_numpy(pcm).cuda()
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl=impl) as m:
+        whole = m.process(x).cpu().numpy()
+        f0, f1 = 123, 301                                   # frames [f0, f1)
+        lo, hi = 170 * f0 - 1, 170 * (f1 - 1) + 512
+        part = m.process(x[lo:hi].clone(), halo=1).cpu().numpy()
+    assert part.shape == (f1 - f0, 13)
+    assert np.array_equal(part, whole[f0:f1])
+
+
+def test_float_lifter(mfcc_amd, wav_pcm):
+    pcm = wav_pcm[:30000]
+    ref = mf.lifter(mf.mfcc_float_ref(pcm, n_cep=32), 22)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, lifter=22.0) as m:
+        got = m.process(pcm)
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
+def test_float_config4_1024_40(mfcc_amd):
+    """Config 4 shape at a small size: nfft 1024, hop 341, 40 mel, power scale = nfft."""
+    pcm = np.stack([mf.synth_pcm(40000, seed=100 + s) for s in range(3)])
+    ref = mf.mfcc_float_ref(pcm, nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
+    with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=13, power_scale=0) as m:
+        assert m.hop == 341
+        got = m.process(pcm)
+    assert got.shape == ref.shape
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
+def test_float_linearity_property_full_size(mfcc_amd):
+    """Size-independent property at config-2 size (10 min): scaling the input by 2 adds
+    exactly 2*sqrt(32) to c0 (log2 of 4x power through the ortho DCT) and leaves c1.. unchanged."""
+    pcm = (mf.synth_pcm(9_600_000, seed=0) // 4).astype(np.int16)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13) as m:
+        a = m.process(pcm)
+        b = m.process((pcm * 2).astype(np.int16))
+    assert a.shape == (56468, 13)
+    assert np.isfinite(a).all()
+    np.testing.assert_allclose(b[:, 0] - a[:, 0], 2 * np.sqrt(32.0), atol=2e-3)
+    assert np.abs(b[:, 1:] - a[:, 1:]).max() < 2e-3
+    # and a sample of frames against the oracle
+    for f in [0, 1, 28000, 56467]:
+        if f == 0:
+            ref = mf.mfcc_float_ref(pcm[:512])[0:1]
+        else:   # a chunk starting one hop earlier gives frame f the right pre-emphasis history
+            ref = mf.mfcc_float_ref(pcm[170 * (f - 1): 170 * f + 512])[1:2]
+        e_max, _ = _err(a[f:f + 1], ref)
+        assert e_max <= TOL, (f, e_max)
+
+
+# ----------------------------------------------------------------------------- fixed
+
+def test_fixed_bit_exact_golden_wav(mfcc_amd, wav_pcm):
+    ref = mx.mfcc_fixed_ref(wav_pcm, nceptrums=32)
+    with mfcc_amd.mfcc_open() as m:                    # host-driver constants, STREAM framing
+        got = m.process_fixed(wav_pcm)
+    assert got.shape == ref.shape == (1047, 32) and got.dtype == np.int16
+    assert np.array_equal(got, ref)
+    assert list(got[0, :13]) == [4059, 1164, -93, -353, -597, -289, -221, -201, -123, -202, -128, 40, -109]
+
+
+@pytest.mark.parametrize("n", [0, 100, 512, 682, 5000])
+def test_fixed_bit_exact_ragged(mfcc_amd, n):
+    pcm = mf.synth_pcm(n, seed=n + 1)
+    ref = mx.mfcc_fixed_ref(pcm, nceptrums=13)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode="stream") as m:
+        got = m.process_fixed(pcm)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_bit_exact_extremes_and_channels(mfcc_amd):
+    rng = np.random.default_rng(5)
+    chans = [rng.integers(-32768, 32768, 6000).astype(np.int16),
+             np.where(np.arange(6000) % 7 < 3, 32767, -32768).astype(np.int16),
+             np.zeros(6000, np.int16),
+             np.full(6000, -32768, np.int16),
+             (3000 * np.sin(np.arange(6000) * 0.3)).astype(np.int16)]
+    pcm = np.stack(chans)
+    ref = mx.mfcc_fixed_ref(pcm, nceptrums=16)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=16, pad_mode="stream") as m:
+        got = m.process_fixed(pcm)
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_bit_exact_config3_full_size(mfcc_amd):
+    """Config 3: synthetic 10 min, STREAM framing, all 56 469 frames bit-exact."""
+    import torch
+    pcm = mf.synth_pcm(9_600_000, seed=0)
+    ref = mx.mfcc_fixed_ref(pcm, nceptrums=13)
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode="stream") as m:
+        got = m.process_fixed(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert got.shape == ref.shape == (56469, 13)
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_other_parameters(mfcc_amd):
+    pcm = mf.synth_pcm(20000, seed=9)
+    for nfft, nfil, ncep in [(256, 16, 16), (1024, 64, 32), (512, 16, 16)]:
+        ref = mx.mfcc_fixed_ref(pcm, nfft=nfft, nfilters=nfil, nceptrums=ncep)
+        with mfcc_amd.MFCC(nfft=nfft, nfilters=nfil, nceptrums=ncep, pad_mode="stream") as m:
+            got = m.process_fixed(pcm)
+        assert np.array_equal(got, ref), (nfft, nfil, ncep)
+
+
+def test_fixed_unsupported_is_an_error_not_a_fallback(mfcc_amd):
+    with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=13) as m:      # 4*40 is not a power of two
+        with pytest.raises(mfcc_amd.MfccHipError) as e:
+            m.process_fixed(np.zeros(4000, np.int16))
+        assert e.value.code == -105
+
+
+def test_convert_wav_to_mfcc_file(mfcc_amd, golden_dir, tmp_path, wav_pcm):
+    """mfcc_convert(sess, x.wav, x.mfcc): raw int16 LE [frame][32] like software/main.c:162-165."""
+    out = tmp_path / "f2.mfcc"
+    with mfcc_amd.mfcc_open() as sess:
+        assert mfcc_amd.mfcc_convert(sess, os.path.join(golden_dir, "f2bjrop1.0.wav"), str(out)) == 0
+    raw = np.fromfile(out, dtype="<i2").reshape(-1, 32)               # view.py:24-25 / lift.py:35-36
+    assert np.array_equal(raw, mx.mfcc_fixed_ref(wav_pcm, nceptrums=32))

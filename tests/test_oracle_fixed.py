@@ -1,0 +1,135 @@
+"""The fixed-point oracle (oracle/mfcc_fixed.py): pinned against the known answers the
+reference's notebook outputs hold (window ROM / curve, filter points), cross-checked
+against the independent structural model, and bounded against the float model.  CPU only.
+
+Parity status: FFT / filterbank / log / DCT integer outputs are *unpinned* against the RTL
+(no simulator, no stored vectors) -- see the header of oracle/mfcc_fixed.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mfcc_fixed as mx
+from oracle import mfcc_fixed_structural as ms
+from oracle import mfcc_float as mf
+
+
+@pytest.fixture(scope="module")
+def ka(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "notebook_known_answers.json")))
+
+
+def test_window_rom_and_curve_known_answers(ka):
+    mem, off_fst, off_lst = mx.window_coeffs(512, 8)
+    assert list(mem) == ka["window_rom_small"]            # MFCC.ipynb cell 17 "small"
+    assert off_fst == 40 and off_lst == ka["window_offsetlast"] == 470
+    curve = mx.window_curve(512, 8)
+    assert list(curve) == ka["window_mysmooth"]           # MFCC.ipynb cell 17 print(mysmooth)
+    assert curve.max() == 510 and list(curve[:4]) == [40, 40, 40, 41]
+
+
+def test_filter_points_known_answer(ka):
+    assert list(mx.filter_points(512, 32, 16e3)) == ka["filter_points"]
+
+
+def test_twiddle_rom_quadrants():
+    re, im = mx.twiddle_rom(512)
+    assert re[0] == 16384 and im[0] == 0
+    assert re[128] == 0 and im[128] == -16384             # exp(-j pi/2)
+    k = np.arange(256)
+    exact = 16384 * np.exp(-2j * np.pi * k / 512)
+    assert np.abs(re - exact.real).max() <= 0.5 + 1e-9
+    assert np.abs(im - exact.imag).max() <= 0.5 + 1e-9
+
+
+CASES = {
+    "speech": lambda wav: wav[3000:3000 + 512 + 170 * 4],
+    "fullscale": lambda wav: np.random.default_rng(1).integers(-32768, 32768, 512 + 170 * 3).astype(np.int16),
+    "square": lambda wav: np.where(np.arange(1200) % 7 < 3, 32767, -32768).astype(np.int16),
+    "zeros": lambda wav: np.zeros(900, np.int16),
+    "short": lambda wav: wav[:100],
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_vectorised_equals_structural_model(name, wav_pcm):
+    pcm = CASES[name](wav_pcm)
+    out, v = mx.mfcc_fixed_ref(pcm, return_stages=True)
+    nf = min(len(out), 4)
+    st = ms.mfcc_frames(pcm, nf)
+    for k in range(nf):
+        for key in ["framed", "windowed", "fft_re", "fft_im", "power", "mel", "log", "dct"]:
+            assert np.array_equal(np.array(st[k][key]), v[key][k]), (name, k, key)
+        assert np.array_equal(np.array(st[k]["curve"]), v["curve"])
+        assert np.array_equal(np.array(st[k]["cep"]), out[k])
+
+
+def test_regression_frame0(wav_pcm):
+    # SURVEY.md 8c scratch-model value, reproduced independently here (unverified vs RTL)
+    out = mx.mfcc_fixed_ref(wav_pcm[:2000])
+    assert list(out[0]) == [4059, 1164, -93, -353, -597, -289, -221, -201, -123, -202, -128, 40, -109]
+
+
+def test_bounded_against_float_model(wav_pcm):
+    """Gross-error bound: fixed FFT within a few LSB of float FFT/512 on the same windowed
+    input; fixed DCT within a few LSB of scipy-style dct/128 of the same log input."""
+    out, v = mx.mfcc_fixed_ref(wav_pcm[:512 + 170 * 40], return_stages=True)
+    w = v["windowed"].astype(np.float64)
+    X = np.fft.fft(w, axis=1)[:, :256] / 512
+    assert np.abs(v["fft_re"] - X.real).max() < 6
+    assert np.abs(v["fft_im"] - X.imag).max() < 6
+    lg = v["log"].astype(np.float64)
+    n = np.arange(32)
+    k = np.arange(32)[:, None]
+    dct = (lg[:, None, :] * np.cos(np.pi * k * (2 * n + 1) / 64)[None]).sum(-1) / 64
+    assert np.abs(v["dct"] - dct).max() < 4
+    # log2: Q4.11 Turner log (12-bit truncating squarings) within 4 LSB, log2(0) := 0
+    mel = v["mel"]
+    nz = mel > 0
+    assert np.abs(v["log"][nz] / 2048.0 - np.log2(mel[nz])).max() < 4.0 / 2048
+    assert (v["log"][~nz] == 0).all()
+
+
+def test_filterbank_impulse_response_is_shifted_by_one_bin():
+    """Appendix A.6: every RTL filter sits one bin later than the notebook's."""
+    W = mf.mel_filterbank(512, 32, 16000)
+    amp = 1 << 16      # amp/2 must stay below the 16-bit wrap
+    resp = np.zeros((32, 256))
+    for k in range(256):
+        p = np.zeros((1, 256), dtype=np.int64)
+        p[0, k] = amp
+        resp[:, k] = mx.filterbank(p)[0] / (amp / 2)
+    d = np.abs(resp[:, 1:] - W[:, :255])
+    # two documented exceptions: segment 0 (diff 0) consumes two bins, so filter 0 is
+    # bins {1, 2} with weight 1 (the notebook's filter 0 is bin 1 only); and the frame's
+    # `last` flag cuts the final filter's last (0.05) tap at bin 255.
+    assert resp[0, 1] == 1.0 and resp[0, 2] == 1.0 and W[0, 0] == 0.0 and W[0, 1] == 1.0
+    assert resp[31, 255] == 0.0 and abs(W[31, 254] - 0.05) < 1e-12
+    d[0, 0] = 0.0
+    d[31, 254] = 0.0
+    assert d.max() < 1e-4
+    assert (resp[:, 0] == 0).all()
+
+
+def test_filterbank_wraps_to_16_bits():
+    p = np.full((1, 256), (1 << 29), dtype=np.int64)
+    m = mx.filterbank(p)[0]
+    assert (m >= 0).all() and (m < 65536).all()
+
+
+def test_stream_frame_count_and_channels(wav_pcm):
+    out = mx.mfcc_fixed_ref(wav_pcm[:5000])
+    assert out.shape == (mf.num_frames_stream(5000), 13) and out.dtype == np.int16
+    two = mx.mfcc_fixed_ref(np.stack([wav_pcm[:5000], wav_pcm[5000:10000]]))
+    assert two.shape == (2, out.shape[0], 13) and np.array_equal(two[0], out)
+    nb = mx.mfcc_fixed_ref(wav_pcm[:5000], pad_mode="notebook")
+    assert np.array_equal(out[:len(nb)], nb)
+
+
+def test_other_parameters_run():
+    x = mf.synth_pcm(4000, 5)
+    a = mx.mfcc_fixed_ref(x, nfft=256, nfilters=16, nceptrums=16)
+    assert a.shape[1] == 16
+    st = ms.mfcc_frames(x, 2, nfft=256, nfilters=16, nceptrums=16)
+    assert np.array_equal(np.array(st[1]["cep"]), a[1])
