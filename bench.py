@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- MFCC frames/sec (512-pt, 32 mel, 13 coeff) on N MI355X; % of HBM roofline.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 16 kHz mono PCM, 10 min per channel
+(9 600 000 samples -> 56 468 frames at 512/170), batched over 64 channels so one launch has
+3.6 M frames (a single 19 MB channel cannot fill the chip).  float32 kernel, 13 coefficients.
+A "step" = one pass of the hot path over the rank's batch, input and output resident in HBM.
+Each rank owns its own batch (weak scaling, frames shard with no data-path collective --
+SURVEY.md 8e); value = frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (algorithmic bytes 392 B/frame over the kernel's
+HIP-event duration, against the 8 TB/s HBM peak) and `cpu_baseline` (the oracle's restatement
+of the reference notebook's NumPy path timed on this host, one 10-min channel).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TFLOPS = 157.3       # vector fp32 peak, for the compute-side note
+NFFT, HOP, NMEL, NCEP = 512, 170, 32, 13
+SAMPLES_PER_CH = 9_600_000     # 10 min @ 16 kHz
+BYTES_PER_FRAME = HOP * 2 + NCEP * 4      # 392 B: each sample read once, each output written once
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=64, help="10-min channels per GPU per step")
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused512"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed", action="store_true", help="bench the fixed-point kernel instead (config 3)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import mfcc_amd
+
+    # ---- synthetic input, generated on the device (white Gaussian, sigma 3000, int16), HBM resident
+    nch = args.channels
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    pcm = torch.empty((nch, SAMPLES_PER_CH), dtype=torch.int16, device=dev)
+    for c in range(nch):
+        x = torch.randn(SAMPLES_PER_CH, generator=g, device=dev, dtype=torch.float32) * 3000.0
+        pcm[c] = x.clamp_(-32768, 32767).to(torch.int16)
+    del x
+
+    pad = "stream" if args.fixed else "notebook"
+    m = mfcc_amd.MFCC(nfft=NFFT, nfilters=NMEL, nceptrums=NCEP, pad_mode=pad, impl=args.impl,
+                      device=local_rank)
+    frames_per_ch = m.num_frames(SAMPLES_PER_CH)
+    frames = frames_per_ch * nch
+    out = torch.empty((nch, frames_per_ch, NCEP), device=dev,
+                      dtype=torch.int16 if args.fixed else torch.float32)
+    run = (lambda: m.process_fixed(pcm, out=out)) if args.fixed else (lambda: m.process(pcm, out=out))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant kernel's launch duration, HIP events on the launch stream (rank-local)
+    kernel_ms = m.time_launches(pcm, out, fixed=args.fixed, warmup=1, iters=max(3, min(args.steps, 10)))
+    bytes_per_frame = (HOP * 2 + NCEP * 2) if args.fixed else BYTES_PER_FRAME
+    achieved = frames * bytes_per_frame / (kernel_ms * 1e-3) / 1e9
+
+    # quick sanity on the timed output (not a parity test: tests/ do that)
+    assert bool(torch.isfinite(out.float()).all()), "non-finite coefficients in bench output"
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import mfcc_fixed, mfcc_float
+        ch0 = pcm[0].cpu().numpy()
+        if args.fixed:
+            tc = time.perf_counter()
+            ref = mfcc_fixed.mfcc_fixed_ref(ch0, nceptrums=NCEP)
+            tc = time.perf_counter() - tc
+            kind_note = "NumPy restatement of the RTL arithmetic (oracle/mfcc_fixed.py), vectorised over frames"
+            ok = bool(np.array_equal(ref, out[0].cpu().numpy()))
+        else:
+            tc = time.perf_counter()
+            ref = mfcc_float.mfcc_notebook(ch0)[:, :NCEP]
+            tc = time.perf_counter() - tc
+            kind_note = ("restatement of notebook/MFCC.ipynb cells 7-39, float64, per-frame loops kept "
+                         "(oracle/mfcc_float.py), single process")
+            got = out[0].cpu().numpy().astype(np.float64)
+            ok = bool(np.abs(got - ref).max() / np.abs(ref).max() < 1e-4)
+        cpu = {"value": round(len(ref) / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "channel 0 of the batch: 10 min synthetic PCM, %d frames, %.1f s; %s; host has %d "
+                         "logical CPUs; GPU output of that channel matches it: %s"
+                         % (len(ref), tc, kind_note, os.cpu_count() or 0, ok)}
+
+    if rank == 0:
+        total_frames = frames * world
+        value = total_frames * args.steps / dt
+        line = {
+            "metric": "MFCC frames/sec (512-pt, 32 mel, 13 coeff)",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32/int64 (RTL fixed-point)" if args.fixed else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("synthetic 16 kHz mono, 10 min per channel, %d channels per GPU, nfft 512 / hop 170 / "
+                             "32 mel / 13 coeff, %s" % (nch, "fixed-point int16 path (configs[2])" if args.fixed
+                                                        else "float32 path (configs[1])")),
+                "frames_per_step_per_gpu": frames,
+                "bytes_per_frame": bytes_per_frame,
+                "parallelism": "frames sharded by channel across %d GPU(s), no data-path collective" % world,
+                "kernel": m.kernel_name(fixed=args.fixed),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel_ms": round(kernel_ms, 4),
+                "note": "algorithmic bytes = frames x %d B / HIP-event kernel time; the path is fp32-VALU/LDS "
+                        "bound (DESIGN.md), so this fraction is reported as asked, not as the binding limit"
+                        % bytes_per_frame,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

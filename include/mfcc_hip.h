@@ -96,9 +96,11 @@ int  mfcc_hip_default_params(mfcc_hip_params *p);
  * Fails with MFCC_HIP_ERROR_NOT_FOUND when no GPU is present: there is no CPU fallback. */
 int  mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out);
 void mfcc_hip_destroy(mfcc_hip_handle *h);
-/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the
- * handle's own stream */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream).  NULL means the HIP
+ * null (default) stream -- which is what torch uses unless told otherwise -- NOT "none". */
 int  mfcc_hip_set_stream(mfcc_hip_handle *h, void *hip_stream);
+/* go back to the handle's own (non-blocking) stream, the state after mfcc_hip_create */
+int  mfcc_hip_use_own_stream(mfcc_hip_handle *h);
 int  mfcc_hip_synchronize(mfcc_hip_handle *h);
 
 /* ---- host-only helpers (work without a GPU) ------------------------------------------ */
@@ -106,7 +108,8 @@ int  mfcc_hip_synchronize(mfcc_hip_handle *h);
 /* frame count for a stream of n_samples under p->pad_mode (`nframes`, main.c:95) */
 int  mfcc_hip_num_frames(const mfcc_hip_params *p, size_t n_samples, size_t *n_frames);
 const char *mfcc_hip_strerror(int err);
-/* hipError_t of the last failing runtime call on this handle (0 if none) */
+/* hipError_t of the last failing runtime call on this handle (0 if none); with h == NULL:
+ * of the last failing mfcc_hip_create on this thread */
 int  mfcc_hip_last_hip_error(const mfcc_hip_handle *h);
 
 /* The constant tables the kernels use, as built on the host (no GPU needed) -- lets the

@@ -68,6 +68,7 @@ SYMBOLS = {
     "mfcc_hip_create": (C.c_int, [C.POINTER(Params), C.POINTER(_H)]),
     "mfcc_hip_destroy": (None, [_H]),
     "mfcc_hip_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "mfcc_hip_use_own_stream": (C.c_int, [_H]),
     "mfcc_hip_synchronize": (C.c_int, [_H]),
     "mfcc_hip_num_frames": (C.c_int, [C.POINTER(Params), _SZ, _PSZ]),
     "mfcc_hip_strerror": (C.c_char_p, [C.c_int]),
@@ -102,6 +103,14 @@ def load():
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C mfcc_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; if ours (linked
+    # against /opt/rocm) were loaded first the process would end up with a runtime torch did
+    # not initialise.  torch is this package's plumbing for device memory and streams, so
+    # load it first and let libmfcc_hip.so bind to the runtime that is already resident.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -133,8 +133,12 @@ class MFCC:
         return self._lib.mfcc_hip_kernel_name(self._h, int(fixed)).decode()
 
     def set_stream(self, stream_ptr):
-        """Launch on a caller-provided hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        """Launch on a caller-provided hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``;
+        0 / None is the HIP null stream, torch's default)."""
         _lib.check(self._lib.mfcc_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_own_stream(self):
+        _lib.check(self._lib.mfcc_hip_use_own_stream(self._h))
 
     def synchronize(self):
         _lib.check(self._lib.mfcc_hip_synchronize(self._h))

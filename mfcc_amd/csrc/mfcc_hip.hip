@@ -419,7 +419,8 @@ const char *mfcc_hip_strerror(int err) {
     }
 }
 
-int mfcc_hip_last_hip_error(const mfcc_hip_handle *h) { return h ? h->last_hip : 0; }
+static thread_local int g_create_hip_error = 0;
+int mfcc_hip_last_hip_error(const mfcc_hip_handle *h) { return h ? h->last_hip : g_create_hip_error; }
 
 int mfcc_hip_get_table(const mfcc_hip_params *p, int which, void *buf, size_t cap, size_t *n_bytes) {
     Resolved r;
@@ -491,7 +492,8 @@ int mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out) {
     int rc = resolve(p, r);
     if (rc) return rc;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MFCC_HIP_ERROR_NOT_FOUND;
+    g_create_hip_error = int(hipGetDeviceCount(&ndev));
+    if (g_create_hip_error != int(hipSuccess) || ndev <= 0) return MFCC_HIP_ERROR_NOT_FOUND;
     int dev = r.device;
     if (dev < 0) {
         if (hipGetDevice(&dev) != hipSuccess) return MFCC_HIP_ERROR_NOT_FOUND;
@@ -534,7 +536,13 @@ void mfcc_hip_destroy(mfcc_hip_handle *h) {
 
 int mfcc_hip_set_stream(mfcc_hip_handle *h, void *hip_stream) {
     if (!h) return MFCC_HIP_ERROR_INVALID_PARAM;
-    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = static_cast<hipStream_t>(hip_stream);      // NULL = the HIP null stream
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_use_own_stream(mfcc_hip_handle *h) {
+    if (!h) return MFCC_HIP_ERROR_INVALID_PARAM;
+    h->stream = h->own_stream;
     return MFCC_HIP_SUCCESS;
 }
 
