@@ -227,7 +227,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.log2_dct = ilog2(4 * r.n_mel);
         h->xt.n_cep = r.n_cep;
     }
-    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, h->fu);
+    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fu);
     return MFCC_HIP_SUCCESS;
 }
 
