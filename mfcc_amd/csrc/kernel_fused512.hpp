@@ -3,31 +3,34 @@
 // DCT-II -> first n_cep (<= 16) -- in one launch.
 //
 // Work unit: a workgroup of 4 waves owns a tile of 16 consecutive frames (the N dimension of
-// v_mfma_f32_16x16x4_f32); wave w transforms frames 4w..4w+3, then the four waves split the
-// mel contraction.  Per tile:
+// v_mfma_f32_16x16x4_f32); wave w transforms frames 4w..4w+3, then the waves split the mel
+// contraction.  Per tile:
 //
-//  pass 1  lane = (q = lane>>4: frame 4w+q, n2 = lane&15).  The lane holds the 32 samples
-//          x[16 n1 + n2] (n1 = 0..31) of its frame -- fetched one tile ahead as one 2-byte-aligned
-//          dword per sample holding (x[i-1], x[i]), so pre-emphasis 32 x[i] - 31 x[i-1] is one
-//          v_dot2c_i32_i16 -- and runs a register-resident REAL 32-point FFT over n1 with the
-//          Hamming window folded into its first butterfly layer (codelets_gen.hpp): Y[k1, n2],
-//          k1 = 0..16.  Columns 0..15 are multiplied by W512^(n2 k1) and written to the wave's LDS
-//          transpose buffer T; column 16 (real) goes to the LDS tile V.
+//  input   the tile's contiguous sample span (16 frames = 3062 samples, ~6 KB) is fetched by the
+//          whole workgroup with two 16-byte loads per thread -- each sample crosses HBM/L2 once per
+//          tile -- one tile ahead, and parked in the LDS sample window S just before the second
+//          barrier of the previous tile.
+//  pass 1  lane = (q = lane>>4: frame 4w+q, n2 = lane&15) picks the 32 pairs (x[i-1], x[i]),
+//          i = 16 n1 + n2, out of S; pre-emphasis 32 x[i] - 31 x[i-1] is one v_dot2c_i32_i16.  Then a
+//          register-resident REAL 32-point FFT over n1 with the Hamming window folded into its first
+//          butterfly layer (codelets_gen.hpp): Y[k1, n2], k1 = 0..16.  Columns 0..15 are multiplied
+//          by W512^(n2 k1) and written to the wave's LDS transpose buffer T; column 16 (real) goes to
+//          the LDS tile V.
 //  pass 2  lane = (q, k1 = lane&15) reads its column from T and runs a complex 16-point FFT over
 //          n2: X[k1 + 32 k2], k2 = 0..15.  The input being real, each of these is a distinct needed
 //          bin (k or 512-k): no real-FFT split step.  |X|^2 goes to the LDS power tile P[frame][bin].
-//  ---- workgroup barrier ----
-//  MFMA    mel energies = W (32 x 256, block-banded) . P as 68 + 4 MFMAs 16x16x4 (A = weights, kept
-//          in registers for the whole kernel; B = P straight from the tile, one ds_read_b64 per two
-//          MFMAs), split four ways by bin range.  Wave 0 also turns column 16 into bins 16+32j with a
-//          16x16 real DFT matrix (4 MFMAs) and feeds them from registers.  Partial sums meet in LDS.
-//  ---- workgroup barrier ----
-//  tail    wave 0: log2, DCT-II as 8 MFMAs whose B operand IS the mel accumulator registers (the K
-//          index is permuted so no lane movement is needed), store n_cep floats per frame.  Waves
-//          1..3 already work on the next tile.
+//  ---- workgroup barrier B1 ----
+//  MFMA    mel energies = W (32 x 256, block-banded) . P as 68 MFMAs 16x16x4 (A = weights, kept in
+//          registers for the whole kernel; B = P straight from the tile, one ds_read_b64 per two
+//          MFMAs), split over waves 1..3 by bin range; partial sums go to LDS.  Wave 0 turns column 16
+//          into bins 16+32j with a 16x16 real DFT matrix (4 MFMAs), feeds them from registers
+//          (4 MFMAs), and -- in the same window -- finishes the PREVIOUS tile: log2, DCT-II as 8 MFMAs
+//          whose B operand IS the mel accumulator registers (the K index is permuted so no lane
+//          movement is needed), store n_cep floats per frame.  Nobody waits for that tail.
+//  ---- workgroup barrier B2 ----
 //
-// HBM traffic per frame: 170 new int16 samples (the 3x overlap between frames is served by
-// L1/L2) + 13 floats out = 392 B.  The kernel is fp32-VALU bound (about 9 k lane-ops per frame),
+// HBM traffic per frame: 170 new int16 samples + 13 floats out = 392 B (plus the 342-sample overlap
+// between consecutive tiles, 11 %).  The kernel is fp32-VALU bound (about 9 k lane-ops per frame),
 // not HBM bound; DESIGN.md has the accounting.
 #pragma once
 
@@ -47,36 +50,38 @@ namespace mfcc_fused {
 constexpr int kNfft = 512, kHop = 170, kMel = 32, kMaxCep = 16;
 constexpr int kTile = 16;                 // frames per workgroup tile (MFMA N dimension)
 constexpr int kWaves = 4;
+constexpr int kTileHop = kTile * kHop;    // 2720 samples between consecutive tiles
 constexpr int kPStride = 260;             // words per frame in the power tile (== 4 mod 64)
 constexpr int kTRow = 34;                 // words per n2 row of a transpose buffer
 constexpr int kTQ = 16 * kTRow;           // 544 words per frame (== 32 mod 64)
 constexpr int kTWave = 4 * kTQ;           // one wave's transpose buffer
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
-constexpr int kAregs = 22;                // MFMA A operands resident per wave
-constexpr int kLdsWords = kTile * kPStride + kWaves * kTWave + kTile * kVStride + 4 * 256;
+constexpr int kAregs = 24;                // MFMA A operands resident per wave
+constexpr int kSHalf = 4096;              // int16 slots of the sample window (256 threads x 2 x 8)
+constexpr int kSLead = 8;                 // the window starts 8 samples before the tile's first
+constexpr int kLdsWords = kTile * kPStride + kWaves * kTWave + kTile * kVStride + 2 * 4 * 256 + kSHalf / 2;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef int int_a2 __attribute__((aligned(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedTables {
     const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 32
     const float2 *tw;     // [16 n2][16 k1]   W512^(n2 k1)
-    const float *a_all;   // [4 waves][22][64] MFMA A operands in the order each wave consumes them
+    const float *a_all;   // [4 waves][24][64] MFMA A operands in the order each wave consumes them
     int n_cep;
 };
 
 // ---- the split of the mel contraction.  Chunk pair C covers bins 8C..8C+7 (two MFMAs: even bins,
 // odd bins).  Filters 0..15 ("block 0") only touch bins < 64, filters 16..31 only bins >= 48
 // (checked by build_tables), so block 0 needs C = 0..7 and block 1 needs C = 6..31.
-//   wave 0: special DFT (4) + special-bin mel (4) + block 0 C 0..2 (6) + DCT (8)      = 22 A operands
-//   wave 1: block 0 C 3..7 (10) + block 1 C 6..10 (10)                                 = 20
-//   wave 2: block 1 C 11..20                                                           = 20
-//   wave 3: block 1 C 21..31                                                           = 22
-constexpr int kW0_B0_LO = 0, kW0_B0_HI = 3;
-constexpr int kW1_B0_LO = 3, kW1_B0_HI = 8, kW1_B1_LO = 6, kW1_B1_HI = 11;
-constexpr int kW2_B1_LO = 11, kW2_B1_HI = 21;
-constexpr int kW3_B1_LO = 21, kW3_B1_HI = 32;
+//   wave 0: special DFT (4) + special-bin mel (4) + DCT (8)                            = 16 A operands
+//   wave 1: block 0 C 0..7 (16) + block 1 C 6..8 (6)                                   = 22
+//   wave 2: block 1 C 9..19                                                            = 22
+//   wave 3: block 1 C 20..31                                                           = 24
+constexpr int kW1_B0_LO = 0, kW1_B0_HI = 8, kW1_B1_LO = 6, kW1_B1_HI = 9;
+constexpr int kW2_B1_LO = 9, kW2_B1_HI = 20;
+constexpr int kW3_B1_LO = 20, kW3_B1_HI = 32;
 
 inline bool supported(int nfft, int hop, int n_mel, int n_cep) {
     return nfft == kNfft && hop == kHop && n_mel == kMel && n_cep >= 1 && n_cep <= kMaxCep;
@@ -129,7 +134,6 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
                 A(0, i0, l) = float(md[size_t(filt) * 257 + bin] * inv);
                 covered[size_t(filt) * 257 + bin] = 1;
             }
-    for (int C = kW0_B0_LO; C < kW0_B0_HI; ++C) chunk(0, i0, C, 0);
     std::vector<double> dd = dct_rows(n_cep, kMel, lifter);                    // [n_cep][32]
     for (int blk = 0; blk < 2; ++blk)
         for (int r = 0; r < 4; ++r, ++i0)
@@ -141,7 +145,7 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     for (int C = kW1_B1_LO; C < kW1_B1_HI; ++C) chunk(1, i1, C, 1);
     for (int C = kW2_B1_LO; C < kW2_B1_HI; ++C) chunk(2, i2, C, 1);
     for (int C = kW3_B1_LO; C < kW3_B1_HI; ++C) chunk(3, i3, C, 1);
-    if (i0 != 22 || i1 != 20 || i2 != 20 || i3 != 22) return false;
+    if (i0 != 16 || i1 != 22 || i2 != 22 || i3 != 24) return false;
     for (int f = 0; f < kMel; ++f)
         for (int k = 0; k < 257; ++k)
             if (md[size_t(f) * 257 + k] != 0.0 && !covered[size_t(f) * 257 + k]) return false;
@@ -166,12 +170,6 @@ inline void bind_tables(const char *b, int n_cep, FusedTables &t) {
 
 // ---- device
 
-__device__ __forceinline__ float preemph_x32(int packed) {
-    // packed = (x[i-1], x[i]) as two int16: 32 x[i] - 31 x[i-1] (exact; 1/32 is in the window table)
-    const s16x2 c = {(short)-31, (short)32};
-    return (float)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, packed), c, 0, false);
-}
-
 __device__ __forceinline__ void wave_lds_fence() {
     // orders this wave's LDS writes before its later LDS reads (the data crosses lanes, not waves)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -180,6 +178,23 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 #define MFCC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Diagnostic build only (-DMFCC_FUSED_STAMPS): per-wave cycle sums of the phases of a tile, written
+// to a buffer of their own that nothing else reads.  No stamp executes in the product build.
+#ifdef MFCC_FUSED_STAMPS
+__device__ unsigned long long g_stamps[8 * 8];     // [wave role 0..3 (+4: count)][phase]
+#define MFCC_STAMP(i)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long now__;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        st_sum[i] += now__ - st_prev;                                                         \
+        st_prev = now__;                                                                      \
+    } while (0)
+#else
+#define MFCC_STAMP(i) do {} while (0)
+#endif
 
 // chunk pairs [LO, HI) of one filter block: accumulate into (mx, my); A operands a[base ...]
 template <int LO, int HI, int BASE>
@@ -192,34 +207,96 @@ __device__ __forceinline__ void mel_chunks(const float2 *pp, const float (&a)[kA
     }
 }
 
-struct TileRef {
-    long long ch, f0;
-    bool inside;
+// Uniform (SGPR) cursor over the workgroup's tiles: tile = ch * tiles_per_ch + t_in.  Advancing by
+// the grid size is an add with carry -- no division in the loop.
+struct Cursor {
+    int ch, t_in;
 };
 
-__device__ __forceinline__ TileRef tile_ref(const mfcc_k::StreamDesc &s, long long tile, long long tiles_per_ch) {
-    TileRef r;
-    r.ch = tile / tiles_per_ch;
-    r.f0 = (tile - r.ch * tiles_per_ch) * kTile;
-    // Interior tiles (every sample index in [first - 1, last] exists) load one unaligned dword per
-    // sample; edge tiles (stream start without history, zero-padded tail) are bounds-checked.
-    r.inside = (r.f0 > 0 || s.halo) && (r.f0 + kTile - 1) * (long long)kHop + kNfft - 1 < s.n_samples;
-    return r;
+struct LaunchGeom {
+    int tiles_per_ch, n_ch, grid_div, grid_mod;      // grid = grid_div * tiles_per_ch + grid_mod
+};
+
+__device__ __forceinline__ void advance(Cursor &c, const LaunchGeom &g) {
+    c.t_in += g.grid_mod;
+    c.ch += g.grid_div;
+    if (c.t_in >= g.tiles_per_ch) {
+        c.t_in -= g.tiles_per_ch;
+        ++c.ch;
+    }
+}
+
+// The tile's sample window: S[j] holds sample (tile_first - kSLead - shift + j) of the channel,
+// j = 0..4095, where shift = 0..7 makes the first 16-byte global load aligned.  Thread tid fetches
+// slots [8 tid, 8 tid + 8) and [2048 + 8 tid, ...).  Windows that stick out of the channel (stream
+// start without history, zero-padded tail) are filled sample by sample with the stream's edge rules.
+struct Fetch {
+    i32x4 v0, v1;
+    int shift;
+};
+
+__device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const Cursor &c, int tid, Fetch &f) {
+    const long long first = (long long)c.t_in * kTileHop - kSLead;                 // channel-relative
+    const int16_t *base = s.pcm + (long long)c.ch * s.ch_stride;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(base + first) & 15) >> 1);  // samples past alignment
+    const bool inside = first - mis >= -(long long)s.halo && first - mis + kSHalf <= s.n_samples;
+    if (inside) {
+        const i32x4 *g = reinterpret_cast<const i32x4 *>(base + first - mis);
+        f.shift = mis;
+        f.v0 = g[tid];
+        f.v1 = g[256 + tid];
+    } else {
+        f.shift = 0;
+        int h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long long i = first + (k < 8 ? 0 : 2048) + 8 * tid + (k & 7);
+            h[k] = mfcc_k::sample_at_i(s, base, i) & 0xFFFF;
+        }
+        f.v0 = (i32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        f.v1 = (i32x4){h[8] | (h[9] << 16), h[10] | (h[11] << 16), h[12] | (h[13] << 16), h[14] | (h[15] << 16)};
+    }
+}
+
+// log2 (MFCC.ipynb cell 36), DCT-II (cells 38-39) and store for one finished tile.  Accumulator
+// register r of block b is filter 16 b + 4 q + r of frame lo == B[k = q][j = lo] of the DCT
+// product, so the mel accumulators feed the DCT MFMAs without any lane movement.
+__device__ __forceinline__ void finish_tile(const mfcc_k::StreamDesc &s, const FusedTables &t, const float *Qb,
+                                            f32x4 m0, f32x4 m1, const float (&a)[kAregs], const Cursor &c,
+                                            int lane, int lo, int q, float *__restrict__ out) {
+    m0 += *reinterpret_cast<const f32x4 *>(Qb + 0 * 256 + lane * 4);
+    m1 += *reinterpret_cast<const f32x4 *>(Qb + 1 * 256 + lane * 4);
+    m1 += *reinterpret_cast<const f32x4 *>(Qb + 2 * 256 + lane * 4);
+    m1 += *reinterpret_cast<const f32x4 *>(Qb + 3 * 256 + lane * 4);
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d0 = MFCC_MFMA(a[8 + r], log2f(m0[r]), d0);
+        d1 = MFCC_MFMA(a[12 + r], log2f(m1[r]), d1);
+    }
+    const long long fr = (long long)c.t_in * kTile + lo;
+    if (fr < s.frames_per_ch) {
+        float *o = out + ((long long)c.ch * s.frames_per_ch + fr) * t.n_cep;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < t.n_cep) o[4 * q + r] = d0[r] + d1[r];
+    }
 }
 
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, long long tiles_per_ch, long long n_tiles,
-                          float *__restrict__ out) {
+void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsWords];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15;          // n2 in pass 1, k1 in pass 2, frame column in the MFMA phase
     const int q = lane >> 4;           // frame 4*wave + q in the passes; K index g in the MFMA phase
 
     float *const Pt = lds;                                         // [16 frames][260]
     float *const Tt = lds + kTile * kPStride + wave * kTWave;      // this wave's [4 q][16 n2][34]
     float *const Vt = lds + kTile * kPStride + kWaves * kTWave;    // [16 frames][18]
-    float *const Qt = Vt + kTile * kVStride;                       // 4 partial-sum blocks of 256 words
+    float *const Qt = Vt + kTile * kVStride;                       // [2][4 partial-sum blocks][256]
+    int16_t *const Sw = reinterpret_cast<int16_t *>(Qt + 2 * 4 * 256);   // sample window, 4096 int16
 
     // per-lane constants, resident for the whole kernel
     float w[32];
@@ -234,49 +311,67 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, long long tiles_p
 
     // the slots of bins 16 (mod 32) are never written (those bins are fed from registers with the
     // chunk weights zeroed) -- make them finite once
-    if (threadIdx.x < 128) Pt[(threadIdx.x >> 3) * kPStride + 16 + 32 * (threadIdx.x & 7)] = 0.0f;
+    if (tid < 128) Pt[(tid >> 3) * kPStride + 16 + 32 * (tid & 7)] = 0.0f;
 
-    // prefetch the first tile's samples
-    int raw[32];
-    long long tile = blockIdx.x;
-    TileRef cur = tile_ref(s, tile < n_tiles ? tile : 0, tiles_per_ch);
-    if (tile < n_tiles && cur.inside) {
-        const int16_t *p = s.pcm + cur.ch * s.ch_stride + (cur.f0 + 4 * wave + q) * (long long)kHop + lo - 1;
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) raw[n1] = *reinterpret_cast<const int_a2 *>(p + 16 * n1);
+    // slot of this lane's sample n1 = 0 in the window, before the per-tile alignment shift
+    const int lane_slot = kSLead + (4 * wave + q) * kHop + lo;
+
+    Cursor cur;
+    cur.ch = (int)(blockIdx.x / (unsigned)g.tiles_per_ch);
+    cur.t_in = (int)(blockIdx.x - (unsigned)cur.ch * (unsigned)g.tiles_per_ch);
+
+    // first tile: fetch and park the sample window
+    Fetch fx;
+    fx.shift = 0;
+    if (cur.ch < g.n_ch) {
+        fetch_window(s, cur, tid, fx);
+        reinterpret_cast<i32x4 *>(Sw)[tid] = fx.v0;
+        reinterpret_cast<i32x4 *>(Sw)[256 + tid] = fx.v1;
     }
+    int shift = fx.shift;
+    __syncthreads();
 
-    for (; tile < n_tiles; tile += gridDim.x) {
+    // wave 0 finishes tile t (log2, DCT, store) inside the MFMA phase of tile t + 1, so that the
+    // other waves never wait for it: its partial sums and the tile's coordinates are carried here
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 keep0 = zero, keep1 = zero;
+    Cursor prev = cur;
+    bool have_prev = false;
+    int par = 0;                                   // which half of Qt this tile's partial sums use
+
+#ifdef MFCC_FUSED_STAMPS
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    while (cur.ch < g.n_ch) {
         // ---------------- pass 1: pre-emphasis + windowed real FFT-32 over n1
         float e[32];
-        if (cur.inside) {
-#pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) e[n1] = preemph_x32(raw[n1]);
-        } else {
-            const int16_t *base = s.pcm + cur.ch * s.ch_stride;
-            const long long i0 = (cur.f0 + 4 * wave + q) * (long long)kHop + lo;
+        {
+            // slot j - 1 holds x[i-1], slot j holds x[i].  Only aligned LDS dwords are read (an unaligned
+            // ds_read_b32 is replayed for hundreds of cycles): dwords (j-1)>>1 and ((j-1)>>1) + 1, then a
+            // funnel shift by 0 or 16 bits puts (x[i-1], x[i]) into one register.
+            const int jm1 = lane_slot + shift - 1;
+            const int *sp = reinterpret_cast<const int *>(Sw) + (jm1 >> 1);
+            const unsigned fsh = (jm1 & 1) * 16u;
+            const s16x2 c3132 = {(short)-31, (short)32};
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) {
-                const long long i = i0 + 16 * n1;
-                const int x0 = mfcc_k::sample_at_i(s, base, i);
-                const int x1 = mfcc_k::sample_at_i(s, base, i - 1);
-                e[n1] = (float)(32 * x0 - 31 * x1);
+                const int d0 = sp[8 * n1], d1 = sp[8 * n1 + 1];
+                const int px = (int)__builtin_amdgcn_alignbit((unsigned)d1, (unsigned)d0, fsh);
+                // 32 x[i] - 31 x[i-1], exact (the 1/32 is in the window table)
+                e[n1] = (float)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, px), c3132, 0, false);
             }
         }
         // next tile's samples fly while this tile is processed
-        const TileRef me = cur;
-        const long long ntile = tile + gridDim.x;
-        if (ntile < n_tiles) {
-            cur = tile_ref(s, ntile, tiles_per_ch);
-            if (cur.inside) {
-                const int16_t *p = s.pcm + cur.ch * s.ch_stride + (cur.f0 + 4 * wave + q) * (long long)kHop + lo - 1;
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) raw[n1] = *reinterpret_cast<const int_a2 *>(p + 16 * n1);
-            }
-        }
+        const Cursor me = cur;
+        advance(cur, g);
+        const bool more = cur.ch < g.n_ch;
+        if (more) fetch_window(s, cur, tid, fx);
+        MFCC_STAMP(6);
 
         float yr[17], yi[17];
         mfcc_codelets::rfft32_win(e, w, yr, yi);
+        MFCC_STAMP(7);
 
         // twiddle W512^(n2 k1) and transpose through LDS: T[q][n2][k1]
         float2 *trow = reinterpret_cast<float2 *>(Tt + q * kTQ + lo * kTRow);
@@ -288,6 +383,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, long long tiles_p
             trow[k1] = make_float2(re, im);
         }
         Vt[(4 * wave + q) * kVStride + lo] = yr[16];
+        MFCC_STAMP(0);
         wave_lds_fence();
 
         // ---------------- pass 2: complex FFT-16 over n2 for column k1 = lo
@@ -300,6 +396,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, long long tiles_p
                 xr[n2] = v.x;
                 xi[n2] = v.y;
             }
+            MFCC_STAMP(1);
             mfcc_codelets::cfft16(xr, xi, zr, zi);
             float *prow_lo = Pt + (4 * wave + q) * kPStride + lo;            // bin k1 + 32 k2
             float *prow_hi = Pt + (4 * wave + q) * kPStride + 32 - lo;       // bin 32 - k1 + 32 (15 - k2)
@@ -308,79 +405,82 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, long long tiles_p
 #pragma unroll
             for (int k2 = 8; k2 < 16; ++k2) prow_hi[32 * (15 - k2)] = fmaf(zr[k2], zr[k2], zi[k2] * zi[k2]);
         }
-        __syncthreads();                         // B1: P and V of all 16 frames are in LDS
+        MFCC_STAMP(2);
+        __syncthreads();                         // B1: P and V of all 16 frames are in LDS; S is consumed
+        MFCC_STAMP(3);
 
         // ---------------- MFMA phase (frame column = lo, K index = q), split by wave
         const float2 *pp = reinterpret_cast<const float2 *>(Pt + lo * kPStride + 2 * q);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 m0 = zero, m1 = zero;              // wave 0 keeps its partial sums in registers
+        float *const Qw = Qt + par * 1024;       // partial sums of this tile
         if (wave == 0) {
+            // column 16 -> bins 16 + 32 j of this tile, fed to both filter blocks from registers
             f32x4 sp = zero;
 #pragma unroll
             for (int k = 0; k < 4; ++k) sp = MFCC_MFMA(a[k], Vt[lo * kVStride + 4 * k + q], sp);
-            f32x4 m0y = zero, m1y = zero;
-            mel_chunks<kW0_B0_LO, kW0_B0_HI, 8>(pp, a, m0, m0y);
+            // meanwhile: the previous tile's partial sums (other half of Qt) are complete since its B2
+            if (have_prev) finish_tile(s, t, Qt + (par ^ 1) * 1024, keep0, keep1, a, prev, lane, lo, q, out);
             const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
             const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
-            m0 = MFCC_MFMA(a[4], s0, m0);
-            m0y = MFCC_MFMA(a[5], s1, m0y);
-            m1 = MFCC_MFMA(a[6], s0, m1);
-            m1y = MFCC_MFMA(a[7], s1, m1y);
-            m0 += m0y;
-            m1 += m1y;
+            f32x4 m0 = MFCC_MFMA(a[4], s0, zero);
+            f32x4 m1 = MFCC_MFMA(a[6], s0, zero);
+            keep0 = MFCC_MFMA(a[5], s1, m0);
+            keep1 = MFCC_MFMA(a[7], s1, m1);
         } else if (wave == 1) {
             f32x4 x0 = zero, y0 = zero, x1 = zero, y1 = zero;
             mel_chunks<kW1_B0_LO, kW1_B0_HI, 0>(pp, a, x0, y0);
-            mel_chunks<kW1_B1_LO, kW1_B1_HI, 10>(pp, a, x1, y1);
-            *reinterpret_cast<f32x4 *>(Qt + 0 * 256 + lane * 4) = x0 + y0;
-            *reinterpret_cast<f32x4 *>(Qt + 1 * 256 + lane * 4) = x1 + y1;
+            mel_chunks<kW1_B1_LO, kW1_B1_HI, 16>(pp, a, x1, y1);
+            *reinterpret_cast<f32x4 *>(Qw + 0 * 256 + lane * 4) = x0 + y0;
+            *reinterpret_cast<f32x4 *>(Qw + 1 * 256 + lane * 4) = x1 + y1;
         } else if (wave == 2) {
             f32x4 x1 = zero, y1 = zero;
             mel_chunks<kW2_B1_LO, kW2_B1_HI, 0>(pp, a, x1, y1);
-            *reinterpret_cast<f32x4 *>(Qt + 2 * 256 + lane * 4) = x1 + y1;
+            *reinterpret_cast<f32x4 *>(Qw + 2 * 256 + lane * 4) = x1 + y1;
         } else {
             f32x4 x1 = zero, y1 = zero;
             mel_chunks<kW3_B1_LO, kW3_B1_HI, 0>(pp, a, x1, y1);
-            *reinterpret_cast<f32x4 *>(Qt + 3 * 256 + lane * 4) = x1 + y1;
+            *reinterpret_cast<f32x4 *>(Qw + 3 * 256 + lane * 4) = x1 + y1;
         }
-        __syncthreads();                         // B2: partial sums are in LDS, P/V may be overwritten
-
-        // ---------------- tail (wave 0): log2 (MFCC.ipynb cell 36), DCT-II (cells 38-39), store.
-        // Accumulator register r of block b is filter 16 b + 4 q + r of frame lo == B[k = q][j = lo]
-        // of the DCT product, so the mel accumulators feed the DCT MFMAs without any lane movement.
-        if (wave == 0) {
-            m0 += *reinterpret_cast<const f32x4 *>(Qt + 0 * 256 + lane * 4);
-            m1 += *reinterpret_cast<const f32x4 *>(Qt + 1 * 256 + lane * 4);
-            m1 += *reinterpret_cast<const f32x4 *>(Qt + 2 * 256 + lane * 4);
-            m1 += *reinterpret_cast<const f32x4 *>(Qt + 3 * 256 + lane * 4);
-            f32x4 d0 = zero, d1 = zero;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                d0 = MFCC_MFMA(a[14 + r], log2f(m0[r]), d0);
-                d1 = MFCC_MFMA(a[18 + r], log2f(m1[r]), d1);
-            }
-            const long long fr = me.f0 + lo;
-            if (fr < s.frames_per_ch) {
-                float *o = out + (me.ch * s.frames_per_ch + fr) * t.n_cep;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * q + r < t.n_cep) o[4 * q + r] = d0[r] + d1[r];
-            }
+        prev = me;
+        have_prev = true;
+        par ^= 1;
+        // park the next tile's sample window (every read of the current one happened before B1)
+        if (more) {
+            reinterpret_cast<i32x4 *>(Sw)[tid] = fx.v0;
+            reinterpret_cast<i32x4 *>(Sw)[256 + tid] = fx.v1;
+            shift = fx.shift;
         }
+        MFCC_STAMP(4);
+        __syncthreads();                         // B2: partial sums and S are in LDS, P/V may be overwritten
+        MFCC_STAMP(5);
     }
+    // the last tile of this workgroup
+    if (wave == 0 && have_prev) finish_tile(s, t, Qt + (par ^ 1) * 1024, keep0, keep1, a, prev, lane, lo, q, out);
+#ifdef MFCC_FUSED_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[wave * 8 + i], st_sum[i]);
+        atomicAdd(&g_stamps[32 + wave], 1ull);
+    }
+#endif
 }
 
 inline const char *kernel_name() { return "mfcc_fused512_kernel"; }
 
-inline void launch(const mfcc_k::StreamDesc &s, const FusedTables &t, float *out, int n_cu,
+// returns false when the problem does not fit the kernel's 32-bit tile arithmetic
+inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, float *out, int n_cu,
                    hipStream_t stream) {
     const long long tiles_per_ch = (s.frames_per_ch + kTile - 1) / kTile;
     const long long n_ch = s.total_frames / s.frames_per_ch;
     const long long n_tiles = tiles_per_ch * n_ch;
+    if (n_tiles >= (1ll << 31) || tiles_per_ch >= (1ll << 26) || n_ch >= (1ll << 31)) return false;
     long long grid = n_tiles < (long long)n_cu * 2 ? n_tiles : (long long)n_cu * 2;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(mfcc_fused512_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t,
-                       tiles_per_ch, n_tiles, out);
+    LaunchGeom g;
+    g.tiles_per_ch = (int)tiles_per_ch;
+    g.n_ch = (int)n_ch;
+    g.grid_div = (int)(grid / tiles_per_ch);
+    g.grid_mod = (int)(grid % tiles_per_ch);
+    hipLaunchKernelGGL(mfcc_fused512_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    return true;
 }
 
 }  // namespace mfcc_fused

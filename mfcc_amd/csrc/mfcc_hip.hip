@@ -268,7 +268,8 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds,
                            h->stream, s, h->xt, static_cast<int16_t *>(d_out));
     } else if (use_fused(h)) {
-        mfcc_fused::launch(s, h->fu, static_cast<float *>(d_out), h->n_cu, h->stream);
+        if (!mfcc_fused::launch(s, h->fu, static_cast<float *>(d_out), h->n_cu, h->stream))
+            return MFCC_HIP_ERROR_UNSUPPORTED;
     } else {
         long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
         long long cap = (long long)h->n_cu * 8;
@@ -636,5 +637,16 @@ int mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfc
     if (n_frames_out) *n_frames_out = nf;
     return MFCC_HIP_SUCCESS;
 }
+
+#ifdef MFCC_FUSED_STAMPS
+// diagnostic build only: copy out and clear the per-phase cycle sums of the fused kernel
+int mfcc_hip_debug_read_stamps(unsigned long long *dst) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_fused::g_stamps), sizeof(unsigned long long) * 64) != hipSuccess)
+        return MFCC_HIP_ERROR_OTHER;
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_fused::g_stamps), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
+    return MFCC_HIP_SUCCESS;
+}
+#endif
 
 }  // extern "C"
