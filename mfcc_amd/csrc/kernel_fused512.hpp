@@ -353,13 +353,17 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             const int jm1 = lane_slot + shift - 1;
             const int *sp = reinterpret_cast<const int *>(Sw) + (jm1 >> 1);
             const unsigned fsh = (jm1 & 1) * 16u;
-            const s16x2 c3132 = {(short)-31, (short)32};
+            const int c3132 = 0x0020ffe1;                  // (int16 -31, int16 32)
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) {
                 const int d0 = sp[8 * n1], d1 = sp[8 * n1 + 1];
                 const int px = (int)__builtin_amdgcn_alignbit((unsigned)d1, (unsigned)d0, fsh);
-                // 32 x[i] - 31 x[i-1], exact (the 1/32 is in the window table)
-                e[n1] = (float)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, px), c3132, 0, false);
+                // 32 x[i] - 31 x[i-1], exact (the 1/32 is in the window table).  The three-operand form
+                // of the dot product: for the builtin hipcc picks v_dot2c (accumulating), which costs an
+                // extra v_mov 0 per sample.
+                int ei;
+                asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(ei) : "v"(px), "s"(c3132));
+                e[n1] = (float)ei;
             }
         }
         // next tile's samples fly while this tile is processed
