@@ -42,6 +42,12 @@ def main():
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused512"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed", action="store_true", help="bench the fixed-point kernel instead (config 3)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                         "multi-rank path on a box with fewer GPUs than ranks: all ranks then share cuda:0)")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also time the host-buffer entry point (H2D + kernel + D2H) on 8 channels; reported "
+                         "as pcie_inclusive, never as value")
     args = ap.parse_args()
 
     import numpy as np
@@ -51,10 +57,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local_rank = 0                       # rehearsal: every rank on the one GPU that is there
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -97,7 +108,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -106,8 +117,36 @@ def main():
     bytes_per_frame = (HOP * 2 + NCEP * 2) if args.fixed else BYTES_PER_FRAME
     achieved = frames * bytes_per_frame / (kernel_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch of this kernel, from the committed rocprofv3 PMC summary of the same
+    # command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; profiles/summarize_rocprof.py)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+            prof = json.load(open(pj))
+            d = prof.get("derived", {})
+            if prof.get("kernel", "").endswith(m.kernel_name(fixed=args.fixed)) and \
+                    d.get("frames_per_launch") == frames and "hbm_traffic_bytes_per_launch" in d:
+                traffic = round(d["hbm_traffic_bytes_per_launch"])
+                traffic_src = os.path.relpath(pj, ROOT)
+                break
+    except Exception:
+        traffic = None
+
     # quick sanity on the timed output (not a parity test: tests/ do that)
     assert bool(torch.isfinite(out.float()).all()), "non-finite coefficients in bench output"
+
+    pcie = None
+    if rank == 0 and args.host_io:
+        hp = pcm[:8].cpu().numpy()
+        m.use_own_stream()
+        m.process_fixed(hp) if args.fixed else m.process(hp)          # warm the staging buffers
+        t1 = time.perf_counter()
+        for _ in range(3):
+            m.process_fixed(hp) if args.fixed else m.process(hp)
+        tp = (time.perf_counter() - t1) / 3
+        pcie = {"value": round(8 * frames_per_ch / tp, 1), "unit": "frames/s",
+                "what": "mfcc_hip_process_i16 on pageable host buffers, 8 channels: H2D + kernel + D2H"}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -169,7 +208,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (algorithmic: %d)" % (frames * bytes_per_frame),
+                "traffic_source": traffic_src,
                 "kernel_ms": round(kernel_ms, 4),
                 "note": "algorithmic bytes = frames x %d B / HIP-event kernel time; the path is fp32-VALU/LDS "
                         "bound (DESIGN.md), so this fraction is reported as asked, not as the binding limit"
@@ -177,6 +218,8 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if pcie:
+            line["pcie_inclusive"] = pcie
         print(json.dumps(line))
     m.close()
     if world > 1:

@@ -59,6 +59,7 @@ constexpr int kVStride = 18;              // words per frame in the column-16 ti
 constexpr int kAregs = 24;                // MFMA A operands resident per wave
 constexpr int kSHalf = 4096;              // int16 slots of the sample window (256 threads x 2 x 8)
 constexpr int kSLead = 8;                 // the window starts 8 samples before the tile's first
+constexpr int kSUsed = 3136;              // slots that are ever read (392 pieces of 8), see fetch_window
 constexpr int kLdsWords = kTile * kPStride + kWaves * kTWave + kTile * kVStride + 2 * 4 * 256 + kSHalf / 2;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -239,12 +240,16 @@ __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const 
     const long long first = (long long)c.t_in * kTileHop - kSLead;                 // channel-relative
     const int16_t *base = s.pcm + (long long)c.ch * s.ch_stride;
     const int mis = (int)((reinterpret_cast<uintptr_t>(base + first) & 15) >> 1);  // samples past alignment
-    const bool inside = first - mis >= -(long long)s.halo && first - mis + kSHalf <= s.n_samples;
+    // only slots 0 .. 3077 are ever read (kSLead + 7 + 15 * 170 + 511 + 1): 392 16-byte pieces, so the
+    // second load is needed from threads 0..135 only -- 3136 samples fetched per 2720-sample tile
+    // step instead of 4096
+    const bool inside = first - mis >= -(long long)s.halo && first - mis + kSUsed <= s.n_samples;
     if (inside) {
         const i32x4 *g = reinterpret_cast<const i32x4 *>(base + first - mis);
         f.shift = mis;
         f.v0 = g[tid];
-        f.v1 = g[256 + tid];
+        f.v1 = (i32x4){0, 0, 0, 0};
+        if (tid < kSUsed / 8 - 256) f.v1 = g[256 + tid];
     } else {
         f.shift = 0;
         int h[16];
