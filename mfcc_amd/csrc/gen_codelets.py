@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """Generates codelets_gen.hpp: straight-line, register-resident FFT codelets for the fused
-512-point MFCC kernel (gfx950).  Run:  python3 gen_codelets.py  (writes next to this file).
+512-point MFCC kernel (gfx950), in PACKED fp32 form.  Run:  python3 gen_codelets.py
 
-Two codelets, both radix-2 decimation-in-time with every trivial twiddle removed and every
-non-trivial twiddle fused Linzer-Feig style (w = c (1 + i t): two FMAs form (1 + i t) b, four
-FMAs add/subtract c times that to a -> 6 FMAs per butterfly instead of 4 mul/add + 4 add):
+Why packed: the kernel is VALU-issue limited (two waves per SIMD, about one vector instruction
+per 4-5 cycles per wave).  A v_pk_fma_f32 / v_pk_add_f32 issues at the cost of the scalar form and
+does two lanes of work, so every complex value lives in one 64-bit register pair (re, im) and a
+complex add, a multiplication by -i, a twiddle rotation ... is ONE instruction.  The re/im cross
+terms use the VOP3P op_sel / neg_lo / neg_hi modifiers, which hipcc does not produce from vector
+expressions -- those ops are emitted as inline asm (pure VALU: no memory counters, no hazards to
+pad); constants go in SGPR pairs ("s" constraint).
 
-  rfft32_win : 32 real inputs e[n] (pre-emphasised samples) and 32 per-lane window constants
-               w[n]  ->  Y[k] = sum_n e[n] w[n] exp(-2 pi i n k / 32), k = 0..16
-               (Y[0], Y[16] real).  The window multiply is folded into the first butterfly
-               layer (a w_a +- b w_b = one mul + two FMAs).
-  cfft16     : 16 complex inputs -> 16 complex outputs, natural order in, natural order out
-               (the bit reversal is register renaming).
+Codelets (radix-2 decimation in time, trivial twiddles removed, non-trivial ones in the 3-op
+Linzer-Feig form  u = b + (-t, t) * (b.y, b.x);  a +- c u):
 
-The generator *traces*: every emitted statement is also evaluated numerically on random
-inputs and the result is checked against numpy.fft before the header is written, so the
-header cannot be stale or wrong without this script failing.
+  cfft16       16 complex in -> 16 complex out, natural order              (74 packed ops)
+  rfft32_tw    real 32-point FFT of e[n] w[n] as a 16-point complex FFT of z[m] = (y[2m], y[2m+1])
+               with the window folded into its first layer, the real-FFT split, and the per-lane
+               twiddle W512^(n2 k1) of the 32 x 16 decomposition applied to columns k1 = 1..15.
+               Outputs t[0..15] (column 0 as (Y0, 0)) and the real column 16.   (about 160 packed ops)
+
+The generator *traces*: every emitted op is evaluated numerically and the results are checked
+against numpy.fft before the header is written.
 """
+import cmath
 import math
 import os
 import sys
@@ -26,219 +32,242 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-class Val:
-    """a real SSA value with a free sign (neg modifiers cost nothing on the VALU)"""
-    __slots__ = ("name", "sgn", "num")
-
-    def __init__(self, name, sgn, num):
-        self.name, self.sgn, self.num = name, sgn, num
-
-    def neg(self):
-        return Val(self.name, -self.sgn, -self.num)
-
-    def ref(self):
-        return self.name if self.sgn > 0 else "-" + self.name
+def lit(c):
+    s = "%.9g" % c
+    if "." not in s and "e" not in s and "inf" not in s:
+        s += ".0"
+    return s + "f"
 
 
-ZERO = None     # exact zero
+class CV:
+    """a complex value held in a v2f register pair (re, im)"""
+    __slots__ = ("name", "num")
+
+    def __init__(self, name, num):
+        self.name, self.num = name, complex(num)
 
 
-class Emit:
+class Gen:
     def __init__(self):
         self.lines = []
+        self.consts = {}
         self.n = 0
         self.ops = 0
 
-    def _new(self, expr, num):
+    def const(self, a, b):
+        """constant pair (a, b) with |a| == |b|: returns (name of the (m, m) pair, neg_lo, neg_hi) so that
+        signs ride on the operand's neg modifiers and the SGPR file holds one pair per magnitude"""
+        m = abs(float(a))
+        assert abs(abs(float(b)) - m) < 1e-12, (a, b)
+        key = round(m, 12)
+        if key not in self.consts:
+            self.consts[key] = "k%d" % len(self.consts)
+        return self.consts[key], int(a < 0), int(b < 0)
+
+    def _new(self, num):
         self.n += 1
-        name = "t%d" % self.n
-        self.lines.append("    const float %s = %s;" % (name, expr))
+        return CV("p%d" % self.n, num)
+
+    def _c(self, stmt_rhs, num):
+        r = self._new(num)
+        self.lines.append("    const v2f %s = %s;" % (r.name, stmt_rhs))
         self.ops += 1
-        return Val(name, +1, num)
+        return r
 
-    @staticmethod
-    def lit(c):
-        s = "%.9g" % c
-        if "." not in s and "e" not in s and "inf" not in s:
-            s += ".0"
-        return s + "f"
+    def _asm(self, op, ins, num, op_sel=None, op_sel_hi=None, neg_lo=None, neg_hi=None, prefix="p"):
+        """ins: list of (constraint, expr); modifier lists have one entry per source operand"""
+        n = len(ins)
+        self.n += 1
+        r = CV("%s%d" % (prefix, self.n), num)
+        mods = ""
+        if op_sel is not None and any(op_sel):
+            mods += " op_sel:[%s]" % ",".join(str(v) for v in op_sel)
+        if op_sel_hi is not None and not all(op_sel_hi):
+            mods += " op_sel_hi:[%s]" % ",".join(str(v) for v in op_sel_hi)
+        if neg_lo is not None and any(neg_lo):
+            mods += " neg_lo:[%s]" % ",".join(str(v) for v in neg_lo)
+        if neg_hi is not None and any(neg_hi):
+            mods += " neg_hi:[%s]" % ",".join(str(v) for v in neg_hi)
+        text = "%s %%0, %s%s" % (op, ", ".join("%%%d" % (i + 1) for i in range(n)), mods)
+        ops = ", ".join('"%s"(%s)' % (c, e) for c, e in ins)
+        self.lines.append('    v2f %s; asm("%s" : "=v"(%s) : %s);' % (r.name, text, r.name, ops))
+        self.ops += 1
+        return r
 
+    # ---- plain elementwise ops (hipcc emits v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
     def add(self, a, b):
-        if a is ZERO:
-            return b
-        if b is ZERO:
-            return a
-        if a.sgn > 0 and b.sgn > 0:
-            return self._new("%s + %s" % (a.name, b.name), a.num + b.num)
-        if a.sgn > 0 and b.sgn < 0:
-            return self._new("%s - %s" % (a.name, b.name), a.num + b.num)
-        if a.sgn < 0 and b.sgn > 0:
-            return self._new("%s - %s" % (b.name, a.name), a.num + b.num)
-        v = self._new("%s + %s" % (a.name, b.name), -(a.num + b.num))
-        return v.neg()
+        return self._c("%s + %s" % (a.name, b.name), a.num + b.num)
 
     def sub(self, a, b):
-        return self.add(a, b.neg() if b is not ZERO else ZERO)
+        return self._c("%s - %s" % (a.name, b.name), a.num - b.num)
 
-    def mulc(self, c, x):
-        """literal constant times value"""
-        if x is ZERO or c == 0.0:
-            return ZERO
-        if c == 1.0:
-            return x
-        if c == -1.0:
-            return x.neg()
-        return self._new("%s * %s" % (self.lit(c * x.sgn), x.name), c * x.num)
+    # ---- complex ops with cross terms
+    def add_mi(self, a, b):          # a + (-i) b = (ar + bi, ai - br)
+        return self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], a.num - 1j * b.num,
+                         op_sel=[0, 1], op_sel_hi=[1, 0], neg_hi=[0, 1])
 
-    def fmac(self, c, x, y):
-        """c * x + y with a literal constant c"""
-        if x is ZERO or c == 0.0:
-            return y
-        if y is ZERO:
-            return self.mulc(c, x)
-        if c == 1.0:
-            return self.add(x, y)
-        if c == -1.0:
-            return self.sub(y, x)
-        cc = c * x.sgn
-        return self._new("fmaf(%s, %s, %s)" % (self.lit(cc), x.name, y.ref()), c * x.num + y.num)
+    def sub_mi(self, a, b):          # a - (-i) b = (ar - bi, ai + br)
+        return self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], a.num + 1j * b.num,
+                         op_sel=[0, 1], op_sel_hi=[1, 0], neg_lo=[0, 1])
 
-    def fmav(self, cname, cnum, x, y, negc=False):
-        """(+-cvar) * x + y with a lane-constant variable"""
-        s = -1.0 if negc else 1.0
-        if x is ZERO:
-            return y
-        sign = s * x.sgn
-        cref = cname if sign > 0 else "-" + cname
-        if y is ZERO:
-            self.n += 1
-            name = "t%d" % self.n
-            self.lines.append("    const float %s = %s * %s;" % (name, cref, x.name))
-            self.ops += 1
-            return Val(name, +1, s * cnum * x.num)
-        return self._new("fmaf(%s, %s, %s)" % (cref, x.name, y.ref()), s * cnum * x.num + y.num)
+    def add_conj(self, a, b):        # a + conj(b)
+        return self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], a.num + b.num.conjugate(), neg_hi=[0, 1])
+
+    def sub_conj(self, a, b):        # a - conj(b)
+        return self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], a.num - b.num.conjugate(), neg_lo=[0, 1])
+
+    def rot(self, b, t):             # (br - t bi, bi + t br) = b (1 + i t)
+        k, nl, nh = self.const(-t, t)
+        return self._asm("v_pk_fma_f32", [("v", b.name), ("s", k), ("v", b.name)], b.num * complex(1.0, t),
+                         op_sel=[1, 0, 0], op_sel_hi=[0, 1, 1], neg_lo=[0, nl, 0], neg_hi=[0, nh, 0])
+
+    def axpy(self, u, c, a):         # a + c u  (c real)
+        k, nl, nh = self.const(c, c)
+        return self._asm("v_pk_fma_f32", [("v", u.name), ("s", k), ("v", a.name)], a.num + c * u.num,
+                         neg_lo=[0, nl, 0], neg_hi=[0, nh, 0])
+
+    def axmy(self, u, c, a):         # a - c u
+        k, nl, nh = self.const(-c, -c)
+        return self._asm("v_pk_fma_f32", [("v", u.name), ("s", k), ("v", a.name)], a.num - c * u.num,
+                         neg_lo=[0, nl, 0], neg_hi=[0, nh, 0])
+
+    def mulc(self, d, g):            # g d for a complex literal g: 2 ops
+        k1, nl1, nh1 = self.const(g.real, g.real)
+        k2, nl2, nh2 = self.const(-g.imag, g.imag)
+        m = self._asm("v_pk_mul_f32", [("v", d.name), ("s", k1)], g.real * d.num, neg_lo=[0, nl1], neg_hi=[0, nh1],
+                      prefix="q")
+        return self._asm("v_pk_fma_f32", [("v", d.name), ("s", k2), ("v", m.name)], g * d.num,
+                         op_sel=[1, 0, 0], op_sel_hi=[0, 1, 1], neg_lo=[0, nl2, 0], neg_hi=[0, nh2, 0])
+
+    def mulv(self, x, tw, twnum, conj=False):
+        """x * tw (or conj(x) * tw) for a per-lane complex variable tw = (c, s): 2 ops"""
+        m = self._asm("v_pk_mul_f32", [("v", x.name), ("v", tw)], x.num.real * twnum, op_sel=[0, 0], op_sel_hi=[0, 1],
+                      prefix="q")
+        xv = x.num.conjugate() if conj else x.num
+        return self._asm("v_pk_fma_f32", [("v", x.name), ("v", tw), ("v", m.name)], xv * twnum,
+                         op_sel=[1, 1, 0], op_sel_hi=[1, 0, 1],
+                         neg_lo=[0, 0 if conj else 1, 0], neg_hi=[0, 1 if conj else 0, 0])
+
+    # ---- butterflies
+    def bf(self, a, b, w):
+        """(a + w b, a - w b)"""
+        c, d = w.real, w.imag
+        if abs(d) < 1e-15 and abs(c - 1.0) < 1e-15:
+            return self.add(a, b), self.sub(a, b)
+        if abs(c) < 1e-15 and abs(d + 1.0) < 1e-15:          # w = -i
+            return self.add_mi(a, b), self.sub_mi(a, b)
+        assert abs(c) > 0.15
+        u = self.rot(b, d / c)
+        return self.axpy(u, c, a), self.axmy(u, c, a)
 
 
-def lf_butterfly(E, a, b, w):
-    """(a + w b, a - w b) for complex a, b (pairs of Val/ZERO) and a literal twiddle w"""
-    ar, ai = a
-    br, bi = b
-    c, d = w.real, w.imag
-    if abs(d) < 1e-15 and abs(c - 1.0) < 1e-15:                 # w = 1
-        return (E.add(ar, br), E.add(ai, bi)), (E.sub(ar, br), E.sub(ai, bi))
-    if abs(c) < 1e-15 and abs(d + 1.0) < 1e-15:                 # w = -i : w b = (bi, -br)
-        return (E.add(ar, bi), E.sub(ai, br)), (E.sub(ar, bi), E.add(ai, br))
-    if abs(c) < 1e-15 and abs(d - 1.0) < 1e-15:                 # w = +i : w b = (-bi, br)
-        return (E.sub(ar, bi), E.add(ai, br)), (E.add(ar, bi), E.sub(ai, br))
-    assert abs(c) > 0.15, "Linzer-Feig needs cos away from 0"
-    t = d / c
-    u = E.fmac(-t, bi, br)          # br - t bi
-    v = E.fmac(t, br, bi)           # bi + t br
-    return ((E.fmac(c, u, ar), E.fmac(c, v, ai)),
-            (E.fmac(-c, u, ar), E.fmac(-c, v, ai)))
-
-
-def cfft_dit(E, xs):
-    """natural-order in, natural-order out radix-2 DIT on a list of complex pairs"""
+def fft_dit(G, xs, leaf):
     n = len(xs)
-    if n == 1:
-        return xs
-    ev = cfft_dit(E, xs[0::2])
-    od = cfft_dit(E, xs[1::2])
+    if n == 2:
+        return list(leaf(xs[0], xs[1]))
+    ev = fft_dit(G, xs[0::2], leaf)
+    od = fft_dit(G, xs[1::2], leaf)
     out = [None] * n
     for k in range(n // 2):
-        w = complex(math.cos(2 * math.pi * k / n), -math.sin(2 * math.pi * k / n))
-        out[k], out[k + n // 2] = lf_butterfly(E, ev[k], od[k], w)
+        out[k], out[k + n // 2] = G.bf(ev[k], od[k], cmath.exp(-2j * math.pi * k / n))
     return out
 
 
-def rfft_dit(E, es, ws):
-    """real-input DIT: es = values, ws = (name, num) window constants or None.
-    Returns X[0..n/2] as complex pairs (imag ZERO where it is exactly 0)."""
-    n = len(es)
-    if n == 2:
-        (a, b) = es
-        if ws is None:
-            return [(E.add(a, b), ZERO), (E.sub(a, b), ZERO)]
-        (wa, wan), (wb, wbn) = ws
-        m = E.fmav(wa, wan, a, ZERO)
-        return [(E.fmav(wb, wbn, b, m), ZERO), (E.fmav(wb, wbn, b, m, negc=True), ZERO)]
-    ev = rfft_dit(E, es[0::2], None if ws is None else ws[0::2])
-    od = rfft_dit(E, es[1::2], None if ws is None else ws[1::2])
-    X = [None] * (n // 2 + 1)
-    for k in range(n // 4 + 1):
-        er, ei = ev[k]
-        orr, oi = od[k]
-        if k == 0:
-            X[0] = (E.add(er, orr), ZERO)
-            X[n // 2] = (E.sub(er, orr), ZERO)
-        elif k == n // 4:
-            X[k] = (er, orr.neg() if orr is not ZERO else ZERO)        # E - i O, both real
-        else:
-            w = complex(math.cos(2 * math.pi * k / n), -math.sin(2 * math.pi * k / n))
-            hi, lo = lf_butterfly(E, (er, ei), (orr, oi), w)           # E + wO, E - wO
-            X[k] = hi
-            X[n // 2 - k] = (lo[0], lo[1].neg() if lo[1] is not ZERO else ZERO)   # conj
-    return X
-
-
-def gen_rfft32():
-    rng = np.random.default_rng(1)
-    e_num = rng.standard_normal(32) * 1000
-    w_num = rng.uniform(0.05, 1.0, 32)
-    E = Emit()
-    es = [Val("e[%d]" % i, +1, e_num[i]) for i in range(32)]
-    ws = [("w[%d]" % i, w_num[i]) for i in range(32)]
-    X = rfft_dit(E, es, ws)
-    ref = np.fft.fft(e_num * w_num)[:17]
-    got = np.array([complex(x[0].num if x[0] is not ZERO else 0.0,
-                            x[1].num if x[1] is not ZERO else 0.0) for x in X])
-    err = np.abs(got - ref).max() / np.abs(ref).max()
-    assert err < 1e-12, err
-    body = list(E.lines)
-    for k, (re, im) in enumerate(X):
-        body.append("    yr[%d] = %s;" % (k, re.ref()))
-        if im is not ZERO:
-            body.append("    yi[%d] = %s;" % (k, im.ref()))
-    src = ("// real 32-point DFT of e[n] * w[n] (window folded into the first layer): %d VALU ops\n"
-           "__device__ __forceinline__ void rfft32_win(const float (&e)[32], const float (&w)[32],\n"
-           "                                           float (&yr)[17], float (&yi)[17]) {\n" % E.ops)
-    src += "\n".join(body) + "\n    yi[0] = 0.0f;\n    yi[16] = 0.0f;\n}\n"
-    return src, E.ops
+def emit_consts(G):
+    return "\n".join("    const v2f %s = {%s, %s};" % (name, lit(m), lit(m)) for m, name in G.consts.items())
 
 
 def gen_cfft16():
     rng = np.random.default_rng(2)
-    x_num = rng.standard_normal(16) + 1j * rng.standard_normal(16)
-    E = Emit()
-    xs = [(Val("xr[%d]" % i, +1, x_num[i].real), Val("xi[%d]" % i, +1, x_num[i].imag)) for i in range(16)]
-    X = cfft_dit(E, xs)
-    ref = np.fft.fft(x_num)
-    got = np.array([complex(a.num, b.num) for a, b in X])
-    err = np.abs(got - ref).max() / np.abs(ref).max()
+    x = rng.standard_normal(16) + 1j * rng.standard_normal(16)
+    G = Gen()
+    X = fft_dit(G, [CV("x[%d]" % i, x[i]) for i in range(16)], lambda a, b: (G.add(a, b), G.sub(a, b)))
+    ref = np.fft.fft(x)
+    err = max(abs(v.num - r) for v, r in zip(X, ref)) / np.abs(ref).max()
     assert err < 1e-12, err
-    body = list(E.lines)
-    for k, (re, im) in enumerate(X):
-        body.append("    zr[%d] = %s;" % (k, re.ref()))
-        body.append("    zi[%d] = %s;" % (k, im.ref()))
-    src = ("// complex 16-point DFT, natural order in and out: %d VALU ops\n"
-           "__device__ __forceinline__ void cfft16(const float (&xr)[16], const float (&xi)[16],\n"
-           "                                       float (&zr)[16], float (&zi)[16]) {\n" % E.ops)
-    src += "\n".join(body) + "\n}\n"
-    return src, E.ops
+    body = emit_consts(G) + "\n" + "\n".join(G.lines) + "\n" + \
+        "\n".join("    z[%d] = %s;" % (k, v.name) for k, v in enumerate(X))
+    src = ("// complex 16-point DFT, natural order in and out: %d packed VALU ops\n"
+           "__device__ __forceinline__ void cfft16(const v2f (&x)[16], v2f (&z)[16]) {\n%s\n}\n" % (G.ops, body))
+    return src, G.ops
+
+
+def gen_rfft32_tw():
+    rng = np.random.default_rng(1)
+    e = rng.standard_normal(32) * 1000
+    w = rng.uniform(0.05, 1.0, 32)              # stands for hamming / 64 (the split's 1/2 is in the table)
+    twn = np.exp(-2j * np.pi * rng.uniform(0, 1, 16))
+    G = Gen()
+    eps = [(CV("ep[%d]" % m, complex(e[2 * m], e[2 * m + 1])), "wp[%d]" % m, complex(w[2 * m], w[2 * m + 1]))
+           for m in range(16)]
+
+    def leaf(a, b):                             # (a wa + b wb, a wa - b wb), elementwise on (y[2m], y[2m+1])
+        (av, awn, aw), (bv, bwn, bw) = a, b
+        ew = lambda v, ww: complex(v.num.real * ww.real, v.num.imag * ww.imag)
+        m = G._c("%s * %s" % (av.name, awn), ew(av, aw))
+        s = G._c("__builtin_elementwise_fma(%s, %s, %s)" % (bv.name, bwn, m.name), m.num + ew(bv, bw))
+        d = G._c("__builtin_elementwise_fma(-%s, %s, %s)" % (bv.name, bwn, m.name), m.num - ew(bv, bw))
+        return s, d
+
+    Z = fft_dit(G, eps, leaf)                   # Z = FFT16 of z[m] = y[2m] + i y[2m+1], y = e w
+    y = e * w
+    zref = np.fft.fft(y[0::2] + 1j * y[1::2])
+    assert max(abs(v.num - r) for v, r in zip(Z, zref)) / np.abs(zref).max() < 1e-12
+
+    # real-FFT split (the common factor 1/2 lives in the window table, so every Y below is 2x the
+    # textbook value; columns 0, 8, 16 are patched up explicitly):
+    #   S = Z[k] + conj Z[16-k], D = Z[k] - conj Z[16-k], T = (-i W32^k) D,
+    #   Y[k] = S + T,  Y[16-k] = conj(S - T)
+    yref = 2.0 * np.fft.fft(y)[:17]
+    T = [None] * 16
+    for k in range(1, 8):
+        S = G.add_conj(Z[k], Z[16 - k])
+        D = G.sub_conj(Z[k], Z[16 - k])
+        Tk = G.mulc(D, -1j * cmath.exp(-2j * math.pi * k / 32))
+        Yk = G.add(S, Tk)
+        Yc = G.sub(S, Tk)                       # conj of Y[16-k]
+        assert abs(Yk.num - yref[k]) < 1e-9 * abs(yref).max()
+        assert abs(Yc.num.conjugate() - yref[16 - k]) < 1e-9 * abs(yref).max()
+        T[k] = G.mulv(Yk, "tw[%d]" % k, twn[k])
+        T[16 - k] = G.mulv(Yc, "tw[%d]" % (16 - k), twn[16 - k], conj=True)
+    # k = 8: Y[8] = conj Z[8] (textbook) -> 2 conj Z[8] in our scaling, so no patch is needed
+    assert abs(2 * Z[8].num.conjugate() - 2 * yref[8] / 2) < 1e-9 * abs(yref).max()
+    T[8] = G.mulv(Z[8], "tw[8]", twn[8], conj=True)
+    T8x = G._c("%s * 2.0f" % T[8].name, 2 * T[8].num)
+    T[8] = T8x
+    # k = 0: (Y0, Y16) = (2a + 2b, 2a - 2b) * 2 ... textbook Y0 = a + b with Z = (a, b) unscaled; ours is 2x
+    k2, _, _ = G.const(2.0, 2.0)
+    a0, b0 = Z[0].num.real, Z[0].num.imag
+    m0 = G._asm("v_pk_mul_f32", [("v", Z[0].name), ("s", k2)], complex(2 * a0, 2 * a0), op_sel=[0, 0], op_sel_hi=[0, 1],
+                prefix="q")
+    P = G._asm("v_pk_fma_f32", [("v", Z[0].name), ("s", k2), ("v", m0.name)], complex(2 * a0 + 2 * b0, 2 * a0 - 2 * b0),
+               op_sel=[1, 0, 0], op_sel_hi=[1, 1, 1], neg_hi=[0, 1, 0])
+    assert abs(P.num.real - yref[0].real) < 1e-9 * abs(yref).max()
+    assert abs(P.num.imag - yref[16].real) < 1e-9 * abs(yref).max()
+    T[0] = G._c("%s * (v2f){1.0f, 0.0f}" % P.name, complex(P.num.real, 0.0))
+    # check the twiddled outputs
+    for k in range(1, 16):
+        assert abs(T[k].num - yref[k] * twn[k]) < 1e-9 * abs(yref).max(), k
+    body = emit_consts(G) + "\n" + "\n".join(G.lines) + "\n" + \
+        "\n".join("    t[%d] = %s;" % (k, v.name) for k, v in enumerate(T)) + "\n    v16 = %s.y;" % P.name
+    src = ("// real 32-point DFT of y[n] = e[n] w[n] (x2: the table holds hamming/64), columns 1..15 times the\n"
+           "// per-lane twiddle tw[k]; t[0] = (Y[0], 0), v16 = Y[16].  %d packed VALU ops\n"
+           "__device__ __forceinline__ void rfft32_tw(const v2f (&ep)[16], const v2f (&wp)[16], const v2f (&tw)[16],\n"
+           "                                          v2f (&t)[16], float &v16) {\n%s\n}\n" % (G.ops, body))
+    return src, G.ops
 
 
 def main():
-    a, na = gen_rfft32()
+    a, na = gen_rfft32_tw()
     b, nb = gen_cfft16()
-    out = ("// GENERATED by gen_codelets.py -- do not edit.  Straight-line FFT codelets (see the\n"
-           "// generator's docstring); every statement was traced numerically against numpy.fft.\n"
+    out = ("// GENERATED by gen_codelets.py -- do not edit.  Packed-fp32 straight-line FFT codelets (see the\n"
+           "// generator's docstring); every op was traced numerically against numpy.fft.\n"
            "#pragma once\n#include <hip/hip_runtime.h>\n\nnamespace mfcc_codelets {\n\n"
-           + a + "\n" + b + "\n}  // namespace mfcc_codelets\n")
+           "typedef float v2f __attribute__((ext_vector_type(2)));\n\n" + a + "\n" + b + "\n}  // namespace mfcc_codelets\n")
     path = os.path.join(HERE, "codelets_gen.hpp")
     with open(path, "w") as f:
         f.write(out)
-    print("rfft32_win: %d ops, cfft16: %d ops -> %s" % (na, nb, path))
+    print("rfft32_tw: %d packed ops, cfft16: %d packed ops -> %s" % (na, nb, path))
 
 
 if __name__ == "__main__":

@@ -67,7 +67,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedTables {
-    const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 32
+    const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 64 (pre-emphasis x32, real-FFT split x2)
     const float2 *tw;     // [16 n2][16 k1]   W512^(n2 k1)
     const float *a_all;   // [4 waves][24][64] MFMA A operands in the order each wave consumes them
     int n_cep;
@@ -95,7 +95,7 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     std::vector<float> win(16 * 32), tw(16 * 16 * 2), aall(size_t(kWaves) * kAregs * 64, 0.0f);
     std::vector<double> w = hamming_periodic(kNfft);
     for (int n2 = 0; n2 < 16; ++n2)
-        for (int n1 = 0; n1 < 32; ++n1) win[n2 * 32 + n1] = float(w[16 * n1 + n2] / 32.0);
+        for (int n1 = 0; n1 < 32; ++n1) win[n2 * 32 + n1] = float(w[16 * n1 + n2] / 64.0);
     for (int n2 = 0; n2 < 16; ++n2)
         for (int k1 = 0; k1 < 16; ++k1) {
             double a = -2.0 * kPi * double(n2 * k1) / 512.0;
@@ -304,12 +304,13 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     int16_t *const Sw = reinterpret_cast<int16_t *>(Qt + 2 * 4 * 256);   // sample window, 4096 int16
 
     // per-lane constants, resident for the whole kernel
-    float w[32];
+    using mfcc_codelets::v2f;
+    v2f wp[16];                                    // window pairs (w[2m], w[2m+1]) of this lane's samples
 #pragma unroll
-    for (int i = 0; i < 32; ++i) w[i] = t.win[lo * 32 + i];
-    float2 tw[16];
+    for (int i = 0; i < 16; ++i) wp[i] = reinterpret_cast<const v2f *>(t.win)[lo * 16 + i];
+    v2f tw[16];                                    // W512^(n2 k1) as (cos, sin)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tw[i] = t.tw[lo * 16 + i];
+    for (int i = 0; i < 16; ++i) tw[i] = reinterpret_cast<const v2f *>(t.tw)[lo * 16 + i];
     float a[kAregs];
 #pragma unroll
     for (int i = 0; i < kAregs; ++i) a[i] = t.a_all[(wave * kAregs + i) * 64 + lane];
@@ -350,7 +351,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
 #endif
     while (cur.ch < g.n_ch) {
         // ---------------- pass 1: pre-emphasis + windowed real FFT-32 over n1
-        float e[32];
+        mfcc_codelets::v2f ep[16];                 // (e[2m], e[2m+1]), e = 32 x[i] - 31 x[i-1]
         {
             // slot j - 1 holds x[i-1], slot j holds x[i].  Only aligned LDS dwords are read (an unaligned
             // ds_read_b32 is replayed for hundreds of cycles): dwords (j-1)>>1 and ((j-1)>>1) + 1, then a
@@ -368,7 +369,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
                 // extra v_mov 0 per sample.
                 int ei;
                 asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(ei) : "v"(px), "s"(c3132));
-                e[n1] = (float)ei;
+                ep[n1 >> 1][n1 & 1] = (float)ei;
             }
         }
         // next tile's samples fly while this tile is processed
@@ -378,41 +379,34 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         if (more) fetch_window(s, cur, tid, fx);
         MFCC_STAMP(6);
 
-        float yr[17], yi[17];
-        mfcc_codelets::rfft32_win(e, w, yr, yi);
+        // windowed real FFT-32 over n1, twiddled by W512^(n2 k1): columns 0..15 as (re, im) pairs, column 16
+        mfcc_codelets::v2f ty[16];
+        float y16;
+        mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
         MFCC_STAMP(7);
 
-        // twiddle W512^(n2 k1) and transpose through LDS: T[q][n2][k1]
-        float2 *trow = reinterpret_cast<float2 *>(Tt + q * kTQ + lo * kTRow);
-        trow[0] = make_float2(yr[0], 0.0f);
+        // transpose through LDS: T[q][n2][k1]
+        mfcc_codelets::v2f *trow = reinterpret_cast<mfcc_codelets::v2f *>(Tt + q * kTQ + lo * kTRow);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) {
-            const float re = fmaf(-yi[k1], tw[k1].y, yr[k1] * tw[k1].x);
-            const float im = fmaf(yi[k1], tw[k1].x, yr[k1] * tw[k1].y);
-            trow[k1] = make_float2(re, im);
-        }
-        Vt[(4 * wave + q) * kVStride + lo] = yr[16];
+        for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
+        Vt[(4 * wave + q) * kVStride + lo] = y16;
         MFCC_STAMP(0);
         wave_lds_fence();
 
         // ---------------- pass 2: complex FFT-16 over n2 for column k1 = lo
         {
-            float xr[16], xi[16], zr[16], zi[16];
-            const float2 *tcol = reinterpret_cast<const float2 *>(Tt + q * kTQ + 2 * lo);
+            mfcc_codelets::v2f x[16], z[16];
+            const mfcc_codelets::v2f *tcol = reinterpret_cast<const mfcc_codelets::v2f *>(Tt + q * kTQ + 2 * lo);
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) {
-                const float2 v = tcol[n2 * (kTRow / 2)];
-                xr[n2] = v.x;
-                xi[n2] = v.y;
-            }
+            for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
             MFCC_STAMP(1);
-            mfcc_codelets::cfft16(xr, xi, zr, zi);
+            mfcc_codelets::cfft16(x, z);
             float *prow_lo = Pt + (4 * wave + q) * kPStride + lo;            // bin k1 + 32 k2
             float *prow_hi = Pt + (4 * wave + q) * kPStride + 32 - lo;       // bin 32 - k1 + 32 (15 - k2)
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) prow_lo[32 * k2] = fmaf(zr[k2], zr[k2], zi[k2] * zi[k2]);
+            for (int k2 = 0; k2 < 8; ++k2) prow_lo[32 * k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
 #pragma unroll
-            for (int k2 = 8; k2 < 16; ++k2) prow_hi[32 * (15 - k2)] = fmaf(zr[k2], zr[k2], zi[k2] * zi[k2]);
+            for (int k2 = 8; k2 < 16; ++k2) prow_hi[32 * (15 - k2)] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
         }
         MFCC_STAMP(2);
         __syncthreads();                         // B1: P and V of all 16 frames are in LDS; S is consumed
