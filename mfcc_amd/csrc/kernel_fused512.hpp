@@ -57,10 +57,11 @@ constexpr int kTQ = 16 * kTRow;           // 544 words per frame (== 32 mod 64)
 constexpr int kTWave = 4 * kTQ;           // one wave's transpose buffer
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
 constexpr int kAregs = 24;                // MFMA A operands resident per wave
-constexpr int kSHalf = 4096;              // int16 slots of the sample window (256 threads x 2 x 8)
+constexpr int kSHalf = 2048;              // slots of the sample window covered by every thread's first piece
 constexpr int kSLead = 8;                 // the window starts 8 samples before the tile's first
-constexpr int kSUsed = 3136;              // slots that are ever read (392 pieces of 8), see fetch_window
-constexpr int kLdsWords = kTile * kPStride + kWaves * kTWave + kTile * kVStride + 2 * 4 * 256 + kSHalf / 2;
+constexpr int kSUsed = 3136;              // fp32 slots of the window (392 pieces of 8), see fetch_window
+constexpr int kSSecond = kSUsed / 8 - 256;   // threads that fetch a second piece (136)
+constexpr int kLdsWords = kTile * kPStride + kWaves * kTWave + kTile * kVStride + 2 * 4 * 256 + kSUsed;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -199,10 +200,11 @@ __device__ unsigned long long g_stamps[8 * 8];     // [wave role 0..3 (+4: count
 
 // chunk pairs [LO, HI) of one filter block: accumulate into (mx, my); A operands a[base ...]
 template <int LO, int HI, int BASE>
-__device__ __forceinline__ void mel_chunks(const float2 *pp, const float (&a)[kAregs], f32x4 &mx, f32x4 &my) {
+__device__ __forceinline__ void mel_chunks(const mfcc_codelets::v2f *pp, const float (&a)[kAregs],
+                                           f32x4 &mx, f32x4 &my) {
 #pragma unroll
     for (int C = LO; C < HI; ++C) {
-        const float2 p = pp[4 * C];
+        const mfcc_codelets::v2f p = pp[4 * C];          // volatile: single ds_read_b64, see pass 2
         mx = MFCC_MFMA(a[BASE + 2 * (C - LO) + 0], p.x, mx);
         my = MFCC_MFMA(a[BASE + 2 * (C - LO) + 1], p.y, my);
     }
@@ -227,12 +229,17 @@ __device__ __forceinline__ void advance(Cursor &c, const LaunchGeom &g) {
     }
 }
 
-// The tile's sample window: S[j] holds sample (tile_first - kSLead - shift + j) of the channel,
-// j = 0..4095, where shift = 0..7 makes the first 16-byte global load aligned.  Thread tid fetches
-// slots [8 tid, 8 tid + 8) and [2048 + 8 tid, ...).  Windows that stick out of the channel (stream
-// start without history, zero-padded tail) are filled sample by sample with the stream's edge rules.
+// The tile's sample window: slot j stands for sample i = tile_first - kSLead - shift + j of the
+// channel, j = 0..3135, where shift = 0..7 makes the first 16-byte global load aligned.  Thread tid
+// fetches slots [8 tid, 8 tid + 8) and, for tid < 136, [2048 + 8 tid, ...), plus the dword holding the
+// sample in front of each piece.  What is parked in LDS is the pre-emphasised sample
+// e[i] = 32 x[i] - 31 x[i-1] as fp32 (exact: |e| < 2^21) -- computed once per sample here instead of
+// once per (frame, sample) in pass 1, where three overlapping frames would each redo it.  Windows that
+// stick out of the channel (stream start without history, zero-padded tail) are filled sample by
+// sample with the stream's edge rules.
 struct Fetch {
     i32x4 v0, v1;
+    int p0, p1;          // dword in front of v0 / v1: its high half is the piece's predecessor sample
     int shift;
 };
 
@@ -246,21 +253,54 @@ __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const 
     const bool inside = first - mis >= -(long long)s.halo && first - mis + kSUsed <= s.n_samples;
     if (inside) {
         const i32x4 *g = reinterpret_cast<const i32x4 *>(base + first - mis);
+        const int *g32 = reinterpret_cast<const int *>(g);
         f.shift = mis;
         f.v0 = g[tid];
+        f.p0 = tid ? g32[4 * tid - 1] : 0;         // slot 0's e is never read (kSLead >= 1)
         f.v1 = (i32x4){0, 0, 0, 0};
-        if (tid < kSUsed / 8 - 256) f.v1 = g[256 + tid];
+        f.p1 = 0;
+        if (tid < kSSecond) {
+            f.v1 = g[256 + tid];
+            f.p1 = g32[1024 + 4 * tid - 1];
+        }
     } else {
         f.shift = 0;
         int h[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const long long i = first + (k < 8 ? 0 : 2048) + 8 * tid + (k & 7);
+            const long long i = first + (k < 8 ? 0 : kSHalf) + 8 * tid + (k & 7);
             h[k] = mfcc_k::sample_at_i(s, base, i) & 0xFFFF;
         }
         f.v0 = (i32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         f.v1 = (i32x4){h[8] | (h[9] << 16), h[10] | (h[11] << 16), h[12] | (h[13] << 16), h[14] | (h[15] << 16)};
+        f.p0 = mfcc_k::sample_at_i(s, base, first + 8 * tid - 1) << 16;
+        f.p1 = mfcc_k::sample_at_i(s, base, first + kSHalf + 8 * tid - 1) << 16;
     }
+}
+
+// e[k] = 32 x[k] - 31 x[k-1] for the 8 samples packed in v, x[-1] = high half of prev.  One
+// v_dot2_i32_i16 per sample (the three-operand form: for the builtin hipcc picks v_dot2c, which costs
+// an extra v_mov 0 per sample); the 1/32 is in the window table.
+__device__ __forceinline__ void preemph8(int prev, const i32x4 &v, float *__restrict__ dst) {
+    const int c3132 = 0x0020ffe1;                  // (int16 -31, int16 32)
+    float e[8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int before = m ? v[m - 1] : prev;
+        const int pe = (int)__builtin_amdgcn_alignbit((unsigned)v[m], (unsigned)before, 16u);   // (x[2m-1], x[2m])
+        int e0, e1;
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e0) : "v"(pe), "s"(c3132));
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e1) : "v"(v[m]), "s"(c3132));
+        e[2 * m] = (float)e0;
+        e[2 * m + 1] = (float)e1;
+    }
+    reinterpret_cast<f32x4 *>(dst)[0] = (f32x4){e[0], e[1], e[2], e[3]};
+    reinterpret_cast<f32x4 *>(dst)[1] = (f32x4){e[4], e[5], e[6], e[7]};
+}
+
+__device__ __forceinline__ void park_window(float *Sf, int tid, const Fetch &f) {
+    preemph8(f.p0, f.v0, Sf + 8 * tid);
+    if (tid < kSSecond) preemph8(f.p1, f.v1, Sf + kSHalf + 8 * tid);
 }
 
 // log2 (MFCC.ipynb cell 36), DCT-II (cells 38-39) and store for one finished tile.  Accumulator
@@ -276,8 +316,10 @@ __device__ __forceinline__ void finish_tile(const mfcc_k::StreamDesc &s, const F
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        d0 = MFCC_MFMA(a[8 + r], log2f(m0[r]), d0);
-        d1 = MFCC_MFMA(a[12 + r], log2f(m1[r]), d1);
+        // v_log_f32 (1 ulp; a denormal mel energy -- far below anything int16 PCM produces --
+        // counts as 0, like an exact zero: -inf)
+        d0 = MFCC_MFMA(a[8 + r], __builtin_amdgcn_logf(m0[r]), d0);
+        d1 = MFCC_MFMA(a[12 + r], __builtin_amdgcn_logf(m1[r]), d1);
     }
     const long long fr = (long long)c.t_in * kTile + lo;
     if (fr < s.frames_per_ch) {
@@ -295,13 +337,16 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = lane & 15;          // n2 in pass 1, k1 in pass 2, frame column in the MFMA phase
-    const int q = lane >> 4;           // frame 4*wave + q in the passes; K index g in the MFMA phase
+    const int q = lane >> 4;           // quarter of the wave; K index g in the MFMA phase
+    // frame of the tile this quarter transforms.  The two quarters of a 32-lane half are 8 frames =
+    // 1360 samples = 16 (mod 32) LDS banks apart, so their ds_read_b32 of the window never collide.
+    const int fr_id = wave + 8 * (q & 1) + 4 * (q >> 1);
 
     float *const Pt = lds;                                         // [16 frames][260]
     float *const Tt = lds + kTile * kPStride + wave * kTWave;      // this wave's [4 q][16 n2][34]
     float *const Vt = lds + kTile * kPStride + kWaves * kTWave;    // [16 frames][18]
     float *const Qt = Vt + kTile * kVStride;                       // [2][4 partial-sum blocks][256]
-    int16_t *const Sw = reinterpret_cast<int16_t *>(Qt + 2 * 4 * 256);   // sample window, 4096 int16
+    float *const Sf = Qt + 2 * 4 * 256;                            // pre-emphasised sample window, fp32
 
     // per-lane constants, resident for the whole kernel
     using mfcc_codelets::v2f;
@@ -320,7 +365,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     if (tid < 128) Pt[(tid >> 3) * kPStride + 16 + 32 * (tid & 7)] = 0.0f;
 
     // slot of this lane's sample n1 = 0 in the window, before the per-tile alignment shift
-    const int lane_slot = kSLead + (4 * wave + q) * kHop + lo;
+    const int lane_slot = kSLead + fr_id * kHop + lo;
 
     Cursor cur;
     cur.ch = (int)(blockIdx.x / (unsigned)g.tiles_per_ch);
@@ -331,8 +376,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     fx.shift = 0;
     if (cur.ch < g.n_ch) {
         fetch_window(s, cur, tid, fx);
-        reinterpret_cast<i32x4 *>(Sw)[tid] = fx.v0;
-        reinterpret_cast<i32x4 *>(Sw)[256 + tid] = fx.v1;
+        park_window(Sf, tid, fx);
     }
     int shift = fx.shift;
     __syncthreads();
@@ -350,27 +394,12 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
     while (cur.ch < g.n_ch) {
-        // ---------------- pass 1: pre-emphasis + windowed real FFT-32 over n1
-        mfcc_codelets::v2f ep[16];                 // (e[2m], e[2m+1]), e = 32 x[i] - 31 x[i-1]
+        // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
+        mfcc_codelets::v2f ep[16];                 // (e[2m], e[2m+1]) of this lane's samples i = 16 n1 + n2
         {
-            // slot j - 1 holds x[i-1], slot j holds x[i].  Only aligned LDS dwords are read (an unaligned
-            // ds_read_b32 is replayed for hundreds of cycles): dwords (j-1)>>1 and ((j-1)>>1) + 1, then a
-            // funnel shift by 0 or 16 bits puts (x[i-1], x[i]) into one register.
-            const int jm1 = lane_slot + shift - 1;
-            const int *sp = reinterpret_cast<const int *>(Sw) + (jm1 >> 1);
-            const unsigned fsh = (jm1 & 1) * 16u;
-            const int c3132 = 0x0020ffe1;                  // (int16 -31, int16 32)
+            const float *sp = Sf + lane_slot + shift;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const int d0 = sp[8 * n1], d1 = sp[8 * n1 + 1];
-                const int px = (int)__builtin_amdgcn_alignbit((unsigned)d1, (unsigned)d0, fsh);
-                // 32 x[i] - 31 x[i-1], exact (the 1/32 is in the window table).  The three-operand form
-                // of the dot product: for the builtin hipcc picks v_dot2c (accumulating), which costs an
-                // extra v_mov 0 per sample.
-                int ei;
-                asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(ei) : "v"(px), "s"(c3132));
-                ep[n1 >> 1][n1 & 1] = (float)ei;
-            }
+            for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
         }
         // next tile's samples fly while this tile is processed
         const Cursor me = cur;
@@ -389,20 +418,23 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         mfcc_codelets::v2f *trow = reinterpret_cast<mfcc_codelets::v2f *>(Tt + q * kTQ + lo * kTRow);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
-        Vt[(4 * wave + q) * kVStride + lo] = y16;
+        Vt[fr_id * kVStride + lo] = y16;
         MFCC_STAMP(0);
         wave_lds_fence();
 
         // ---------------- pass 2: complex FFT-16 over n2 for column k1 = lo
         {
             mfcc_codelets::v2f x[16], z[16];
-            const mfcc_codelets::v2f *tcol = reinterpret_cast<const mfcc_codelets::v2f *>(Tt + q * kTQ + 2 * lo);
+            // volatile: keeps these 16 ds_read_b64 from being paired into ds_read2_b64, which moves
+            // half the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table)
+            const mfcc_codelets::v2f *tcol =
+                reinterpret_cast<const mfcc_codelets::v2f *>(Tt + q * kTQ + 2 * lo);
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
             MFCC_STAMP(1);
             mfcc_codelets::cfft16(x, z);
-            float *prow_lo = Pt + (4 * wave + q) * kPStride + lo;            // bin k1 + 32 k2
-            float *prow_hi = Pt + (4 * wave + q) * kPStride + 32 - lo;       // bin 32 - k1 + 32 (15 - k2)
+            float *prow_lo = Pt + fr_id * kPStride + lo;            // bin k1 + 32 k2
+            float *prow_hi = Pt + fr_id * kPStride + 32 - lo;       // bin 32 - k1 + 32 (15 - k2)
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) prow_lo[32 * k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
 #pragma unroll
@@ -413,7 +445,8 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         MFCC_STAMP(3);
 
         // ---------------- MFMA phase (frame column = lo, K index = q), split by wave
-        const float2 *pp = reinterpret_cast<const float2 *>(Pt + lo * kPStride + 2 * q);
+        const mfcc_codelets::v2f *pp =
+            reinterpret_cast<const mfcc_codelets::v2f *>(Pt + lo * kPStride + 2 * q);
         float *const Qw = Qt + par * 1024;       // partial sums of this tile
         if (wave == 0) {
             // column 16 -> bins 16 + 32 j of this tile, fed to both filter blocks from registers
@@ -448,8 +481,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         par ^= 1;
         // park the next tile's sample window (every read of the current one happened before B1)
         if (more) {
-            reinterpret_cast<i32x4 *>(Sw)[tid] = fx.v0;
-            reinterpret_cast<i32x4 *>(Sw)[256 + tid] = fx.v1;
+            park_window(Sf, tid, fx);
             shift = fx.shift;
         }
         MFCC_STAMP(4);
