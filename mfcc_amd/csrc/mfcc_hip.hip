@@ -641,7 +641,7 @@ int mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfc
 #ifdef MFCC_FUSED_STAMPS
 // diagnostic build only: copy out and clear the per-phase cycle sums of the fused kernel
 int mfcc_hip_debug_read_stamps(unsigned long long *dst) {
-    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_fused::g_stamps), sizeof(unsigned long long) * 64) != hipSuccess)
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_fused::g_stamps), sizeof(unsigned long long) * 64) != hipSuccess)  // 4 x 12 phases + 16
         return MFCC_HIP_ERROR_OTHER;
     unsigned long long z[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_fused::g_stamps), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
