@@ -173,6 +173,53 @@ def fft_dit(G, xs, leaf):
     return out
 
 
+ISSUE_DISTANCE = 5      # a lone wave issues a dependent packed op ~9 clocks after its producer and an
+                        # independent one every ~6 (scratch/pkdep.hip on MI355X): keep >= 4 other ops between
+
+
+def schedule(lines, first_use_order=None):
+    """List-schedule straight-line statements `v2f NAME = f(operands)` so that every statement comes at
+    least ISSUE_DISTANCE slots after the statements that define its operands whenever the DAG has that
+    much parallelism; priority = longest path to a sink.  hipcc keeps the order of inline-asm
+    statements unless registers force it not to, and it has no latency model for them."""
+    import re
+    defs, uses = [], []
+    for ln in lines:
+        m = re.match(r"\s*(?:const )?v2f (\w+)", ln)
+        assert m, ln
+        defs.append(m.group(1))
+        rest = ln[m.end():]
+        uses.append(set(re.findall(r"\b[pq]\d+\b", rest)) - {m.group(1)})
+    idx = {d: i for i, d in enumerate(defs)}
+    preds = [[idx[u] for u in us if u in idx] for us in uses]
+    succs = [[] for _ in lines]
+    for i, ps in enumerate(preds):
+        for j in ps:
+            succs[j].append(i)
+    height = [0] * len(lines)
+    for i in reversed(range(len(lines))):
+        height[i] = 1 + max([height[j] for j in succs[i]], default=0)
+    placed, slot_of, order = set(), {}, []
+    remaining = set(range(len(lines)))
+    slot = 0
+    while remaining:
+        ready = [i for i in remaining if all(j in placed for j in preds[i])]
+        def earliest(i):
+            return max([slot_of[j] + ISSUE_DISTANCE for j in preds[i]], default=0)
+        ok = [i for i in ready if earliest(i) <= slot]
+        if ok:
+            pick = max(ok, key=lambda i: (height[i], -i))
+        else:
+            pick = min(ready, key=lambda i: (earliest(i), -height[i], i))
+        order.append(pick)
+        placed.add(pick)
+        slot_of[pick] = slot
+        remaining.discard(pick)
+        slot += 1
+    tight = sum(1 for i in order for j in preds[i] if slot_of[i] - slot_of[j] < ISSUE_DISTANCE)
+    return [lines[i] for i in order], tight
+
+
 def emit_consts(G):
     return "\n".join("    const v2f %s = {%s, %s};" % (name, lit(m), lit(m)) for m, name in G.consts.items())
 
@@ -185,7 +232,9 @@ def gen_cfft16():
     ref = np.fft.fft(x)
     err = max(abs(v.num - r) for v, r in zip(X, ref)) / np.abs(ref).max()
     assert err < 1e-12, err
-    body = emit_consts(G) + "\n" + "\n".join(G.lines) + "\n" + \
+    lines, tight = schedule(G.lines)
+    print("cfft16: %d dependences closer than %d slots" % (tight, ISSUE_DISTANCE))
+    body = emit_consts(G) + "\n" + "\n".join(lines) + "\n" + \
         "\n".join("    z[%d] = %s;" % (k, v.name) for k, v in enumerate(X))
     src = ("// complex 16-point DFT, natural order in and out: %d packed VALU ops\n"
            "__device__ __forceinline__ void cfft16(const v2f (&x)[16], v2f (&z)[16]) {\n%s\n}\n" % (G.ops, body))
@@ -248,7 +297,9 @@ def gen_rfft32_tw():
     # check the twiddled outputs
     for k in range(1, 16):
         assert abs(T[k].num - yref[k] * twn[k]) < 1e-9 * abs(yref).max(), k
-    body = emit_consts(G) + "\n" + "\n".join(G.lines) + "\n" + \
+    lines, tight = schedule(G.lines)
+    print("rfft32_tw: %d dependences closer than %d slots" % (tight, ISSUE_DISTANCE))
+    body = emit_consts(G) + "\n" + "\n".join(lines) + "\n" + \
         "\n".join("    t[%d] = %s;" % (k, v.name) for k, v in enumerate(T)) + "\n    v16 = %s.y;" % P.name
     src = ("// real 32-point DFT of y[n] = e[n] w[n] (x2: the table holds hamming/64), columns 1..15 times the\n"
            "// per-lane twiddle tw[k]; t[0] = (Y[0], 0), v16 = Y[16].  %d packed VALU ops\n"

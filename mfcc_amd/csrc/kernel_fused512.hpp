@@ -467,9 +467,12 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         f32x4 x0 = zero, y0 = zero, x1 = zero, y1 = zero;
         if (role == 1) {
             // column 16 -> bins 16 + 32 j of this tile, fed to both filter blocks from registers
-            f32x4 sp = zero;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sp = MFCC_MFMA(ax[k], Vt[lo * kVStride + 4 * k + q], sp);
+            // two chains of two: the K = 16 contraction has no other ILP
+            f32x4 sp = MFCC_MFMA(ax[0], Vt[lo * kVStride + 0 + q], zero);
+            f32x4 sp2 = MFCC_MFMA(ax[1], Vt[lo * kVStride + 4 + q], zero);
+            sp = MFCC_MFMA(ax[2], Vt[lo * kVStride + 8 + q], sp);
+            sp2 = MFCC_MFMA(ax[3], Vt[lo * kVStride + 12 + q], sp2);
+            sp += sp2;
             const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
             const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
             x0 = MFCC_MFMA(ax[4], s0, x0);
