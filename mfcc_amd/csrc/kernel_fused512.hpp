@@ -209,21 +209,28 @@ __device__ unsigned long long g_stamps[4 * 12 + 16];   // [wave][12 phases], the
 #endif
 
 // Uniform (SGPR) cursor over the workgroup's tiles: tile = ch * tiles_per_ch + t_in.  Advancing by
-// the grid size is an add with carry -- no division in the loop.
+// the grid size is a handful of scalar adds with one carry -- no multiply or division in the loop
+// (a wave's scalar instructions issue ~10 clocks apart; the multiply form of this cost ~450 clocks
+// per tile in every wave).
 struct Cursor {
     int ch, t_in;
+    const int16_t *ptr;      // the tile's first sample: s.pcm + ch * ch_stride + t_in * kTileHop
 };
 
 struct LaunchGeom {
     int tiles_per_ch, n_ch, grid_div, grid_mod;      // grid = grid_div * tiles_per_ch + grid_mod
+    long long step_ptr, wrap_ptr;                    // samples: ptr step per grid stride / extra step on carry
+    int t_lo, t_hi;                                  // tiles t_lo <= t_in <= t_hi have their window inside the channel
 };
 
 __device__ __forceinline__ void advance(Cursor &c, const LaunchGeom &g) {
     c.t_in += g.grid_mod;
     c.ch += g.grid_div;
+    c.ptr += g.step_ptr;
     if (c.t_in >= g.tiles_per_ch) {
         c.t_in -= g.tiles_per_ch;
         ++c.ch;
+        c.ptr += g.wrap_ptr;
     }
 }
 
@@ -242,34 +249,34 @@ struct Fetch {
 
 // uniform (scalar) geometry of a tile's window; every wave computes it, fetchers or not
 struct Window {
-    const int16_t *base;     // the channel
-    long long first;         // channel-relative index of slot 0 (before the shift)
+    const int16_t *ptr;      // the tile's first sample
+    int t_in;
     int shift;
     bool inside;             // whole window (and the dword in front of it) lies inside the channel
 };
 
-__device__ __forceinline__ Window window_of(const mfcc_k::StreamDesc &s, const Cursor &c) {
+__device__ __forceinline__ Window window_of(const Cursor &c, const LaunchGeom &g) {
     Window w;
-    w.first = (long long)c.t_in * kTileHop;
-    w.base = s.pcm + (long long)c.ch * s.ch_stride;
-    const int mis = (int)((reinterpret_cast<uintptr_t>(w.base + w.first) & 15) >> 1);  // samples past alignment
-    // -2: the dword in front of piece 0
-    w.inside = w.first - mis - 2 >= -(long long)s.halo && w.first - mis + kSUsed <= s.n_samples;
+    w.ptr = c.ptr;
+    w.t_in = c.t_in;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(c.ptr) & 15) >> 1);   // samples past alignment
+    // t_lo / t_hi (host): first - 7 - 2 >= -halo (the dword in front of piece 0) and first + kSUsed <= n_samples
+    w.inside = c.t_in >= g.t_lo && c.t_in <= g.t_hi;
     w.shift = w.inside ? mis : 0;
     return w;
 }
 
 __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch &f) {
-    const long long first = w.first;
-    const int16_t *base = w.base;
     if (w.inside) {
-        const i32x4 *g = reinterpret_cast<const i32x4 *>(base + first - w.shift);
+        const i32x4 *g = reinterpret_cast<const i32x4 *>(w.ptr - w.shift);
         const int *g32 = reinterpret_cast<const int *>(g);
         f.v0 = g[u];
         f.p0 = g32[4 * u - 1];
         f.v1 = g[kFetchers + u];
         f.p1 = g32[4 * (kFetchers + u) - 1];
     } else {
+        const long long first = (long long)w.t_in * kTileHop;      // channel-relative
+        const int16_t *base = w.ptr - first;
         int h[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -385,12 +392,13 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     Cursor cur;
     cur.ch = (int)(blockIdx.x / (unsigned)g.tiles_per_ch);
     cur.t_in = (int)(blockIdx.x - (unsigned)cur.ch * (unsigned)g.tiles_per_ch);
+    cur.ptr = s.pcm + (long long)cur.ch * s.ch_stride + (long long)cur.t_in * kTileHop;
 
     // first tile: fetch and park the sample window
     Fetch fx;
     int shift = 0;
     if (cur.ch < g.n_ch) {
-        const Window w0 = window_of(s, cur);
+        const Window w0 = window_of(cur, g);
         shift = w0.shift;
         if (role != 0) {
             fetch_window(s, w0, fetcher, fx);
@@ -426,7 +434,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         const bool more = cur.ch < g.n_ch;
         int next_shift = 0;
         if (more) {
-            const Window wn = window_of(s, cur);
+            const Window wn = window_of(cur, g);
             next_shift = wn.shift;
             if (role != 0) fetch_window(s, wn, fetcher, fx);
         }
@@ -534,6 +542,13 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, float *out
     g.n_ch = (int)n_ch;
     g.grid_div = (int)(grid / tiles_per_ch);
     g.grid_mod = (int)(grid % tiles_per_ch);
+    g.step_ptr = (long long)g.grid_div * s.ch_stride + (long long)g.grid_mod * kTileHop;
+    g.wrap_ptr = s.ch_stride - tiles_per_ch * (long long)kTileHop;
+    // window of tile t_in: samples [t_in * kTileHop - mis - 2, t_in * kTileHop - mis + kSUsed), mis <= 7
+    g.t_lo = (int)((9 - (long long)s.halo + kTileHop - 1) / kTileHop);
+    if (g.t_lo < 0) g.t_lo = 0;
+    const long long hi = (s.n_samples - kSUsed) / kTileHop;
+    g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
     hipLaunchKernelGGL(mfcc_fused512_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
     return true;
 }
