@@ -54,8 +54,10 @@ constexpr int kTile = 16;                 // frames per workgroup tile (MFMA N d
 constexpr int kWaves = 4;
 constexpr int kTileHop = kTile * kHop;    // 2720 samples between consecutive tiles
 constexpr int kTRow = 34;                 // words per n2 row of the transpose tile
-constexpr int kTFrame = 16 * kTRow + 4;   // 548 words per frame (== 36 mod 64: pass 2's 16 frames x 2 columns
-                                          // of a 32-lane half fall on 32 distinct 8-byte bank pairs)
+constexpr int kTFrame = 16 * kTRow + 2;   // 546 words per frame (== 2 mod 32): pass 2 reads one column of 16
+                                          // frames per 16 lanes with ds_read2_b64 (32-bank addressing, 16 lanes
+                                          // per access) -- 16 distinct 8-byte bank pairs; 548 cost a 2-way
+                                          // conflict on every one of them (SQ_LDS_BANK_CONFLICT)
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
 constexpr int kAmel = 17;                 // mel A operands per wave: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
 constexpr int kAextra = 8;                // role operands: role 0 DCT (8); role 1 column-16 DFT (4) + its mel (4)
