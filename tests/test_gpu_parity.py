@@ -113,6 +113,51 @@ def test_float_halo_sharding_is_seamless(mfcc_amd, impl):
     assert np.array_equal(part, whole[f0:f1])
 
 
+def test_fused_kernel_alignment_shifts_and_edges(mfcc_amd):
+    """The fused 512/170/32 kernel fetches 16-byte aligned windows and shifts them by 0..7 samples:
+    drive every shift (channel base and stride at all residues mod 8 samples), windows that stick
+    out of the stream at both ends, a history halo, and enough tiles for the per-workgroup pipeline
+    -- against the generic kernel (same fp32 contract) and, on a slice, the oracle."""
+    import torch
+    nfr = 16 * 37 + 5                                   # 37 full tiles + a ragged one per channel
+    n = 170 * (nfr - 1) + 512
+    nch = 9
+    rng = np.random.default_rng(77)
+    for base_off in range(8):
+        stride = n + 3 + base_off                       # odd strides: every channel lands on another residue
+        flat = torch.from_numpy(rng.integers(-32768, 32767, size=base_off + stride * nch + 64,
+                                             dtype=np.int16)).cuda()
+        view = torch.as_strided(flat, (nch, n), (stride, 1), storage_offset=base_off)
+        assert (view.data_ptr() // 2) % 8 == (flat.data_ptr() // 2 + base_off) % 8
+        for halo in (0, 1):
+            with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl="fused512") as mfu, \
+                    mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, impl="generic") as mge:
+                a = mfu.process(view, halo=halo).cpu().numpy()
+                b = mge.process(view, halo=halo).cpu().numpy()
+            assert a.shape == b.shape == (nch, mf.num_frames_notebook(n - halo), 13)
+            assert np.isfinite(a).all()
+            e_max, e_l2 = _err(a, b)
+            assert e_max <= 2e-5 and e_l2 <= 2e-5, (base_off, halo, e_max, e_l2)
+            if halo == 0:
+                a0 = a
+    # oracle on one misaligned channel (uniform noise keeps every mel energy > 0)
+    ref = mf.mfcc_float_ref(view[3].cpu().numpy())
+    e_max, e_l2 = _err(a0[3], ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
+@pytest.mark.parametrize("ncep", [1, 4, 12, 16])
+def test_fused_kernel_other_ncep_and_stream_padding(mfcc_amd, ncep):
+    pcm = np.stack([mf.synth_pcm(170 * 50 + 512 + 37, seed=200 + s) for s in range(3)])
+    ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream")
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=ncep, pad_mode="stream", impl="fused512") as m:
+        assert m.kernel_name().endswith("fused512_kernel")
+        got = m.process(pcm)
+    assert got.shape == ref.shape
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
 def test_float_lifter(mfcc_amd, wav_pcm):
     pcm = wav_pcm[:30000]
     ref = mf.lifter(mf.mfcc_float_ref(pcm, n_cep=32), 22)
