@@ -36,8 +36,8 @@ BYTES_PER_FRAME = HOP * 2 + NCEP * 4      # 392 B: each sample read once, each o
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=64, help="10-min channels per GPU per step")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused512"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -179,6 +179,34 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed);
 int  mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfcc_out,
                           int fixed, size_t *n_frames_out);
 
+/* ---- serial wire format of the FPGA's coefficient stream (host only, no GPU) ---------------
+ * mfcc/misc/magic.py:9-41 (MagicInserter: 0xa55a in front of every frame's coefficients),
+ * software/serial.c:13-14,89-122 (expect_magic: byte-wise resynchronisation, big endian),
+ * software/cepstrum.c:15-71 (cepstrum_get_column: magic, then n_cep big-endian int16).       */
+
+/* bytes mfcc_hip_serial_pack writes for n_frames frames: n_frames * 2 * (n_cep + 1) */
+size_t mfcc_hip_serial_packed_size(size_t n_frames, int n_cep);
+
+/* cep [n_frames][n_cep] int16 (what process_fixed_i16 returns) -> the byte stream the FPGA's
+ * UART carries: per frame 0xa5 0x5a, then n_cep coefficients high byte first.             */
+int  mfcc_hip_serial_pack(const int16_t *cep, size_t n_frames, int n_cep, uint8_t *out, size_t out_capacity);
+
+/* The receiver of cepstrum_get_column, on a buffer instead of a file descriptor: scan for 0xa5
+ * followed by 0x5a exactly like expect_magic (a 0xa5 not followed by 0x5a drops both bytes), then
+ * take n_cep big-endian int16; repeat.  Stops at max_frames or when the buffer cannot hold another
+ * whole column.  *n_frames_out = columns decoded, *consumed_out = bytes of `bytes` used up.   */
+int  mfcc_hip_serial_unpack(const uint8_t *bytes, size_t n_bytes, int n_cep, int16_t *cep, size_t max_frames,
+                            size_t *n_frames_out, size_t *consumed_out);
+
+/* cepstrum_eval_power (software/cepstrum.c:161-183): `window` is the circular buffer of
+ * n_frames x n_cep int16, `head` the element index of its oldest entry (0 for a linear window).
+ * Sums the squares of the elements head + i, i = size/3, size/3 + n_cep, ... < 2 size/3 (size =
+ * n_frames * n_cep; the first coefficient of the middle third of the frames when size/3 is a
+ * multiple of n_cep, as in the reference's 16 x 93 window).  *power_out gets the sum (64-bit; the
+ * reference accumulates in a 32-bit int); returns 1 if it reaches the reference's threshold 1e8,
+ * 0 if not, negative on bad arguments.                                                       */
+int  mfcc_hip_eval_power(const int16_t *window, int n_cep, int n_frames, size_t head, long long *power_out);
+
 #ifdef __cplusplus
 }
 #endif

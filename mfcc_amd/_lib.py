@@ -63,6 +63,11 @@ _H = C.c_void_p
 _SZ = C.c_size_t
 _PSZ = C.POINTER(C.c_size_t)
 SYMBOLS = {
+    "mfcc_hip_serial_packed_size": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "mfcc_hip_serial_pack": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]),
+    "mfcc_hip_serial_unpack": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "mfcc_hip_eval_power": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_longlong)]),
     "mfcc_hip_abi_version": (C.c_int, []),
     "mfcc_hip_default_params": (C.c_int, [C.POINTER(Params)]),
     "mfcc_hip_create": (C.c_int, [C.POINTER(Params), C.POINTER(_H)]),

@@ -638,6 +638,69 @@ int mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfc
     return MFCC_HIP_SUCCESS;
 }
 
+// ---- serial wire format + power gate (host only): magic.py:9-41, serial.c:89-122, cepstrum.c:15-71,161-183
+size_t mfcc_hip_serial_packed_size(size_t n_frames, int n_cep) {
+    return n_cep > 0 ? n_frames * 2 * (size_t(n_cep) + 1) : 0;
+}
+
+int mfcc_hip_serial_pack(const int16_t *cep, size_t n_frames, int n_cep, uint8_t *out, size_t out_capacity) {
+    if (n_cep <= 0 || (n_frames && (!cep || !out))) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (out_capacity < mfcc_hip_serial_packed_size(n_frames, n_cep)) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    uint8_t *p = out;
+    for (size_t f = 0; f < n_frames; ++f) {
+        *p++ = 0xa5;                                   // MagicInserter: 0xa55a first, high byte first on the wire
+        *p++ = 0x5a;
+        for (int c = 0; c < n_cep; ++c) {
+            const uint16_t v = (uint16_t)cep[f * n_cep + c];
+            *p++ = (uint8_t)(v >> 8);
+            *p++ = (uint8_t)(v & 0xff);
+        }
+    }
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_serial_unpack(const uint8_t *bytes, size_t n_bytes, int n_cep, int16_t *cep, size_t max_frames,
+                           size_t *n_frames_out, size_t *consumed_out) {
+    if (n_cep <= 0 || (n_bytes && !bytes) || (max_frames && !cep)) return MFCC_HIP_ERROR_INVALID_PARAM;
+    size_t pos = 0, frames = 0, consumed = 0;
+    const size_t col = size_t(n_cep) * 2;
+    while (frames < max_frames) {
+        // expect_magic: skip to 0xa5; the byte after it must be 0x5a, otherwise both are dropped
+        size_t q = pos;
+        bool aligned = false;
+        while (!aligned) {
+            while (q < n_bytes && bytes[q] != 0xa5) ++q;
+            if (q + 1 >= n_bytes) { q = n_bytes; break; }
+            aligned = bytes[q + 1] == 0x5a;
+            q += 2;
+        }
+        if (!aligned || q + col > n_bytes) break;
+        for (int c = 0; c < n_cep; ++c)
+            cep[frames * n_cep + c] = (int16_t)(uint16_t)((bytes[q + 2 * c] << 8) | bytes[q + 2 * c + 1]);
+        pos = q + col;
+        consumed = pos;
+        ++frames;
+    }
+    if (n_frames_out) *n_frames_out = frames;
+    if (consumed_out) *consumed_out = consumed;
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_eval_power(const int16_t *window, int n_cep, int n_frames, size_t head, long long *power_out) {
+    if (!window || n_cep <= 0 || n_frames <= 0) return MFCC_HIP_ERROR_INVALID_PARAM;
+    const size_t size = size_t(n_cep) * size_t(n_frames);
+    if (head >= size) return MFCC_HIP_ERROR_INVALID_PARAM;
+    const size_t first = 1 * size / 3, last = 2 * size / 3;
+    long long power = 0;
+    for (size_t i = first; i < last; i += size_t(n_cep)) {
+        size_t k = head + i;
+        if (k >= size) k -= size;
+        power += (long long)window[k] * (long long)window[k];
+    }
+    if (power_out) *power_out = power;
+    return power >= 100000000ll ? 1 : 0;               // POWER_THRESHOLD, cepstrum.c:13
+}
+
 #ifdef MFCC_FUSED_STAMPS
 // diagnostic build only: copy out and clear the per-phase cycle sums of the fused kernel
 int mfcc_hip_debug_read_stamps(unsigned long long *dst) {
