@@ -15,6 +15,7 @@
 
 #include "../../include/mfcc_hip.h"
 #include "kernels_generic.hpp"
+#include "kernel_fixed512.hpp"
 #include "kernel_fused512.hpp"
 #include "tables.hpp"
 
@@ -107,11 +108,13 @@ struct mfcc_hip_handle {
     int n_cu = 0;
     bool fixed_ok = false;
     bool fused_ok = false;
+    bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
     void *arena = nullptr;
     mfcc_k::FloatTables ft{};
     mfcc_k::FixedTables xt{};
     mfcc_fused::FusedTables fu{};
+    mfcc_fixed512::Tables x5{};
     // scratch for the host-buffer entry points
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -173,6 +176,7 @@ int build_tables(mfcc_hip_handle *h) {
 
     // ---- fixed
     size_t o_cv = 0, o_xt = 0, o_xd = 0, o_xs = 0, o_xc = 0, o_xo = 0, o_xw = 0;
+    int x5_w_total = 0;
     FxMel fm;
     h->fixed_ok = fixed_supported(r);
     if (h->fixed_ok) {
@@ -190,7 +194,15 @@ int build_tables(mfcc_hip_handle *h) {
         if (xw.empty()) xw.push_back(0u);
         o_cv = a.put(cv); o_xt = a.put(t1); o_xd = a.put(t2);
         o_xs = a.put(xs.start); o_xc = a.put(xs.count); o_xo = a.put(xs.off); o_xw = a.put(xw);
+        x5_w_total = (int)xw.size();
     }
+    // ---- fused fixed-point kernel (the RTL's own configuration)
+    std::vector<char> x5_blob;
+    uint32_t x5_tw[4] = {0, 0, 0, 0};
+    h->fixed512_ok = h->fixed_ok && mfcc_fixed512::supported(r.nfft, r.n_mel, r.n_cep) &&
+                     x5_w_total <= mfcc_fixed512::kMelWMax && mfcc_fixed512::build_tables(x5_blob, x5_tw);
+    size_t o_x5 = 0;
+    if (h->fixed512_ok) o_x5 = a.put(x5_blob);
 
     // ---- fused 512/170/32 kernel tables
     std::vector<char> fused_blob;
@@ -228,6 +240,15 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.n_cep = r.n_cep;
     }
     if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fu);
+    if (h->fixed512_ok) {
+        mfcc_fixed512::bind_tables(b + o_x5, h->x5);
+        h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];
+        h->x5.mel_start = h->xt.mel_start; h->x5.mel_count = h->xt.mel_count; h->x5.mel_off = h->xt.mel_off;
+        h->x5.mel_w = h->xt.mel_w;
+        h->x5.mel_shift = fm.shift;
+        h->x5.mel_w_total = x5_w_total;
+        h->x5.n_cep = r.n_cep;
+    }
     return MFCC_HIP_SUCCESS;
 }
 
@@ -259,7 +280,9 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
 
     HIP_TRY(h, hipSetDevice(h->device));
     const long long total = s.total_frames;
-    if (fixed) {
+    if (fixed && h->fixed512_ok) {
+        mfcc_fixed512::launch(s, h->x5, static_cast<int16_t *>(d_out), h->n_cu, h->stream);
+    } else if (fixed) {
         long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
         long long cap = (long long)h->n_cu * 8;
         if (blocks > cap) blocks = cap;
@@ -601,7 +624,7 @@ int mfcc_hip_time_dev(mfcc_hip_handle *h, int fixed, const void *d_pcm, size_t n
 
 const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
-    if (fixed) return "mfcc_fixed_kernel";
+    if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return mfcc_fused::kernel_name();
     return "mfcc_float_generic_kernel";
 }
