@@ -36,9 +36,11 @@ namespace mfcc_fixed512 {
 
 constexpr int kNfft = 512, kMel = 32, kWaves = 4;
 constexpr int kXWords = 512 + 64;        // transpose buffer: index i lives at i + 8 (i >> 6)
-constexpr int kMelWMax = 1024;           // packed filterbank weights held in LDS (sum of row lengths)
+constexpr int kMelWMax = 1024;           // packed filterbank weights held in LDS (sum of row lengths, + 8 slack)
+constexpr int kRawWords = 65 * 4;        // raw-sample staging: 65 aligned 16-byte pieces cover a frame + history
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t __attribute__((may_alias)) i16_alias;     // LDS staged as 16-byte pieces, read back as samples
 
 struct Tables {
     const int *curve8;        // [64 lanes][8]   window curve of sample lane + 64 m
@@ -129,20 +131,41 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (x0 +- a) >> 1 with 16-bit wrap on packed x0; a1 / a2 are the rotated x1 (re, im)
+// (x0 +- a) >> 1 with 16-bit wrap on packed x0; a1 / a2 are the rotated x1 (re, im).  8 VALU ops: four
+// SDWA adds that sign-extend x0's halves on the fly, and per output a shift plus an SDWA shift that
+// lands in the high word (the 16-bit wrap is the truncation to a half).
 __device__ __forceinline__ void combine(uint32_t p0, int a1, int a2, uint32_t &o0, uint32_t &o1) {
-    const int x0r = (int)(short)(p0 & 0xffffu), x0i = (int)p0 >> 16;
-    const uint32_t y0r = (uint32_t)((x0r + a1) >> 1) & 0xffffu, y0i = (uint32_t)((x0i + a2) >> 1);
-    const uint32_t y1r = (uint32_t)((x0r - a1) >> 1) & 0xffffu, y1i = (uint32_t)((x0i - a2) >> 1);
-    o0 = y0r | (y0i << 16);
-    o1 = y1r | (y1i << 16);
+    int t0, t1, t2, t3;
+    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t0) : "v"(p0), "v"(a1));
+    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t1) : "v"(p0), "v"(a1));
+    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(t2) : "v"(p0), "v"(a2));
+    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(t3) : "v"(p0), "v"(a2));
+    const int one = 1;
+    uint32_t r0 = (uint32_t)t0 >> 1, r1 = (uint32_t)t1 >> 1;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r0) : "s"(one), "v"(t2));
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r1) : "s"(one), "v"(t3));
+    o0 = r0;
+    o1 = r1;
+}
+
+// x1r*twr - x1i*twi + 8191 (operand A) / x1r*twi + x1i*twr + 8191 (operand B): the three-operand form of
+// the dot product (the builtin becomes v_dot2c, which needs a v_mov of the bias first)
+__device__ __forceinline__ int rot14(uint32_t p1, uint32_t tw) {
+    const int bias = 8191;
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(p1), "v"(tw), "s"(bias));
+    return r >> 14;
 }
 
 // general butterfly, misc/fft.py:140-192
 __device__ __forceinline__ void bfly(uint32_t &p0, uint32_t &p1, uint32_t twa, uint32_t twb) {
-    const int a1 = __builtin_amdgcn_sdot2(as_s16x2(p1), as_s16x2(twa), 8191, false) >> 14;
-    const int a2 = __builtin_amdgcn_sdot2(as_s16x2(p1), as_s16x2(twb), 8191, false) >> 14;
-    combine(p0, a1, a2, p0, p1);
+    combine(p0, rot14(p1, twa), rot14(p1, twb), p0, p1);
 }
 
 // twiddle T[0] = (16384, 0): (x * 16384 + 8191) >> 14 == x
@@ -173,6 +196,27 @@ struct FrameCursor {
     long long f;
 };
 
+// Where a frame's samples are: p = the history sample n0 - 1, mis = samples between the 16-byte
+// boundary below p and p.  fast: the 65 aligned pieces from that boundary lie inside the channel, so the
+// frame can be fetched with one 16-byte load per lane (+1) -- otherwise (stream start without history,
+// zero-padded tail) it is read sample by sample with the stream's edge rules.
+struct FrameGeom {
+    const int16_t *base;
+    long long n0;
+    int mis;
+    bool fast;
+};
+
+__device__ __forceinline__ FrameGeom geom_of(const mfcc_k::StreamDesc &s, const FrameCursor &c) {
+    FrameGeom q;
+    q.base = s.pcm + (long long)c.ch * s.ch_stride;
+    q.n0 = c.f * (long long)s.hop;
+    q.mis = (int)((reinterpret_cast<uintptr_t>(q.base + q.n0 - 1) & 15) >> 1);
+    const long long lo = q.n0 - 1 - q.mis;
+    q.fast = lo >= -(long long)s.halo && lo + 65 * 8 <= s.n_samples;
+    return q;
+}
+
 struct Geom {
     long long frames_per_ch;
     int n_ch;
@@ -183,12 +227,14 @@ struct Geom {
 __global__ __launch_bounds__(64 * kWaves)
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t xbuf[kWaves][kXWords];     // gather / transposes / power
+    __shared__ __attribute__((aligned(16))) uint32_t rawbuf[kWaves][kRawWords];
     __shared__ uint32_t melw[kMelWMax];
     __shared__ int melv[kWaves][kMel];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *X = xbuf[wave];
+    uint32_t *Rb = rawbuf[wave];
 
     // read-only tables: filterbank weights in LDS, the rest in registers for the whole kernel
     for (int i = tid; i < t.mel_w_total; i += 64 * kWaves) melw[i] = t.mel_w[i];
@@ -214,27 +260,60 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     c.ch = (int)(wid / g.frames_per_ch);
     c.f = wid - (long long)c.ch * g.frames_per_ch;
 
+    // the next frame's samples are fetched one frame ahead: 16 bytes per lane, lane 63 also takes piece 64
+    // piece 64 is fetched by lane 63 through an index the compiler cannot see through: a provably uniform
+    // address would be turned into s_load_dwordx4, whose base address must be dword aligned -- ours
+    // is only 2-byte aligned plus an odd offset, and SMEM drops the low bits of the base
+    int lane_op = lane;
+    asm volatile("" : "+v"(lane_op));
+    // the next frame's samples are fetched one frame ahead: 16 bytes per lane, lane 63 also takes piece 64
+    uint4 raw = make_uint4(0, 0, 0, 0), raw64 = raw;
+    FrameGeom q = geom_of(s, c);
+    if (c.ch < g.n_ch && q.fast) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(q.base + q.n0 - 1 - q.mis);
+        raw = src[lane];
+        if (lane == 63) raw64 = src[lane_op + 1];
+    }
+    i16_alias *const R16 = reinterpret_cast<i16_alias *>(Rb);
+
     while (c.ch < g.n_ch) {
-        const int16_t *base = s.pcm + (long long)c.ch * s.ch_stride;
-        const long long n0 = c.f * (long long)s.hop;
+        FrameCursor nc = c;
+        nc.f += g.step_f;
+        nc.ch += g.step_ch;
+        if (nc.f >= g.frames_per_ch) {
+            nc.f -= g.frames_per_ch;
+            ++nc.ch;
+        }
+        // ---- this frame's samples n0 - 1 .. n0 + 511 into the LDS staging buffer, sample n0 - 1 at slot `first`
+        int first;
+        if (q.fast) {
+            reinterpret_cast<uint4 *>(Rb)[lane] = raw;
+            if (lane == 63) reinterpret_cast<uint4 *>(Rb)[64] = raw64;
+            first = q.mis;
+        } else {
+            // stream start without history / zero-padded tail: sample by sample with the stream's edge rules
+            for (int k = lane; k < kNfft + 1; k += 64) R16[k] = (int16_t)mfcc_k::sample_at_i(s, q.base, q.n0 - 1 + k);
+            first = 0;
+        }
+        wave_fence();
+        // ---- the next frame's samples start their way from HBM
+        const bool more = nc.ch < g.n_ch;
+        FrameGeom qn = geom_of(s, nc);
+        if (more && qn.fast) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(qn.base + qn.n0 - 1 - qn.mis);
+            raw = src[lane];
+            if (lane == 63) raw64 = src[lane_op + 1];
+        }
 
         // ---- pre-emphasis and window of sample a = lane + 64 m, parked as int16 for the bit-reversed gather
         {
-            const bool inside = n0 - 1 >= -(long long)s.halo && n0 + kNfft <= s.n_samples;
             uint16_t *W = reinterpret_cast<uint16_t *>(X);
+            const i16_alias *r = R16 + first + lane;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const int a = lane + 64 * m;
-                int x0, o;
-                if (inside) {
-                    x0 = base[n0 + a];
-                    o = base[n0 + a - 1];
-                } else {
-                    x0 = mfcc_k::sample_at_i(s, base, n0 + a);
-                    o = mfcc_k::sample_at_i(s, base, n0 + a - 1);
-                }
+                const int o = r[64 * m], x0 = r[64 * m + 1];
                 const int y = (int)(short)((x0 + (o >> 5) - o) & 0xffff);       // preemph.py:24
-                W[a] = (uint16_t)((y * curve[m]) >> 9);                         // window.py:84
+                W[lane + 64 * m] = (uint16_t)(__mul24(y, curve[m]) >> 9);       // window.py:84
             }
         }
         wave_fence();
@@ -290,8 +369,17 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
         // ---- filterbank, closed form (tables.hpp: fx_mel): two lanes per filter, then log2 (log.py:33-102)
         {
             unsigned long long acc = 0;
-            for (int j = (lane & 1); j < m_count; j += 2)
-                acc += (unsigned long long)X[m_start + j] * (unsigned long long)melw[m_off + j];
+            // four bins per trip, so that their LDS reads are in flight together
+            for (int j = (lane & 1); j < m_count; j += 8) {
+                unsigned long long part = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + 2 * u;
+                    const uint32_t w = jj < m_count ? melw[m_off + jj] : 0u;
+                    part += (unsigned long long)X[m_start + jj] * (unsigned long long)w;
+                }
+                acc += part;
+            }
             const unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
             const unsigned lo2 = (unsigned)__shfl_xor((int)lo, 1), hi2 = (unsigned)__shfl_xor((int)hi, 1);
             acc += ((unsigned long long)hi2 << 32) | lo2;
@@ -327,18 +415,14 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
                 v = up ? p1 : p0;
             }
             // last stage: x0 = 0 (lower half), x1 = v, twiddle index lane; Re of y0 only
-            const int a1 = __builtin_amdgcn_sdot2(as_s16x2(v), as_s16x2(twd[12]), 8191, false) >> 14;
+            const int a1 = rot14(v, twd[12]);
             if (lane < t.n_cep)
                 out[((long long)c.ch * g.frames_per_ch + c.f) * t.n_cep + lane] = (int16_t)(a1 >> 1);
         }
         wave_fence();
 
-        c.f += g.step_f;
-        c.ch += g.step_ch;
-        if (c.f >= g.frames_per_ch) {
-            c.f -= g.frames_per_ch;
-            ++c.ch;
-        }
+        c = nc;
+        q = qn;
     }
 }
 

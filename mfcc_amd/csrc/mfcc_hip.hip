@@ -200,7 +200,7 @@ int build_tables(mfcc_hip_handle *h) {
     std::vector<char> x5_blob;
     uint32_t x5_tw[4] = {0, 0, 0, 0};
     h->fixed512_ok = h->fixed_ok && mfcc_fixed512::supported(r.nfft, r.n_mel, r.n_cep) &&
-                     x5_w_total <= mfcc_fixed512::kMelWMax && mfcc_fixed512::build_tables(x5_blob, x5_tw);
+                     x5_w_total + 8 <= mfcc_fixed512::kMelWMax && mfcc_fixed512::build_tables(x5_blob, x5_tw);
     size_t o_x5 = 0;
     if (h->fixed512_ok) o_x5 = a.put(x5_blob);
 
