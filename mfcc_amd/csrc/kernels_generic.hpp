@@ -60,6 +60,13 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 
 // One workgroup = 4 waves, each wave owns one frame per iteration.
 // LDS per wave: two ping-pong buffers of M complex (Stockham), later reused for power/mel.
+// every LDS buffer below is private to a wave: a wavefront-scope fence orders its lanes' accesses
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NFFT>
 __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s, FloatTables t,
                                                                   float *__restrict__ out) {
@@ -70,14 +77,18 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // frame cursor of this wave: (ch, f), advanced by the number of waves in the grid without a division
     const long long waves_total = (long long)gridDim.x * kWavesPerBlock;
-    const long long iters = (s.total_frames + waves_total - 1) / waves_total;
+    const long long step_ch = waves_total / s.frames_per_ch, step_f = waves_total % s.frames_per_ch;
+    long long fid = (long long)blockIdx.x * kWavesPerBlock + wave;
+    long long ch = fid / s.frames_per_ch, f = fid % s.frames_per_ch;
 
-    for (long long it = 0; it < iters; ++it) {
-        const long long fid = it * waves_total + (long long)blockIdx.x * kWavesPerBlock + wave;
-        const bool valid = fid < s.total_frames;
-        const long long ch = valid ? fid / s.frames_per_ch : 0;
-        const long long f = valid ? fid % s.frames_per_ch : 0;
+    for (; fid < s.total_frames; fid += waves_total, ch += step_ch, f += step_f) {
+        if (f >= s.frames_per_ch) {
+            f -= s.frames_per_ch;
+            ++ch;
+        }
+        const bool valid = true;
         const int16_t *base = s.pcm + ch * s.ch_stride;
         const long long n0 = f * (long long)s.hop;
 
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             float y = x0 - 0.96875f * x1;
             za[i] = y * t.window[i];
         }
-        __syncthreads();
+        wave_sync();
 
         // Stockham autosort FFT of length M: radix-4 passes, one radix-2 pass if needed
         float2 *src = bufA[wave];
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
                 dst[j0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
                 dst[j0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
             }
-            __syncthreads();
+            wave_sync();
             float2 *tmp = src; src = dst; dst = tmp;
         }
         if (Ns < M) {                       // remaining radix-2 pass (M = 2 * 4^n)
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
                 dst[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
                 dst[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
             }
-            __syncthreads();
+            wave_sync();
             float2 *tmp = src; src = dst; dst = tmp;
         }
 
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             float xi = ei + (w.x * oi + w.y * orr);
             P[k] = xr * xr + xi * xi;
         }
-        __syncthreads();
+        wave_sync();
 
         // mel filterbank (cells 30, 36) + log2
         if (lane < t.n_mel) {
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             for (int j = 0; j < cnt; ++j) acc = fmaf(P[st + j], w[j], acc);
             melv[wave][lane] = log2f(acc);
         }
-        __syncthreads();
+        wave_sync();
 
         // DCT-II, first n_cep rows (cells 38-39)
         if (valid && lane < t.n_cep) {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             for (int n = 0; n < t.n_mel; ++n) acc = fmaf(d[n], melv[wave][n], acc);
             out[fid * t.n_cep + lane] = acc;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

@@ -200,6 +200,36 @@ def test_float_linearity_property_full_size(mfcc_amd):
         assert e_max <= TOL, (f, e_max)
 
 
+def test_periodic_speech_stream_repeats_bit_for_bit(mfcc_amd, wav_pcm):
+    """Size-independent property on a speech-like spectrum at config-2 size: tile a prefix of the
+    golden wav whose length is a multiple of the hop (170 q samples).  Frame k + q sees exactly the
+    samples of frame k (and, from the second period on, the same pre-emphasis history), so both
+    kernels must repeat their output bit for bit with period q frames -- across tiles, alignment
+    shifts and workgroups.  One period is checked against the oracles."""
+    import torch
+    q = 1000
+    period = wav_pcm[:170 * q]
+    reps = 9_600_000 // len(period) + 1
+    pcm = np.tile(period, reps)[:9_600_000]
+    x = torch.from_numpy(pcm).cuda()
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode="stream") as m:
+        fl = m.process(x).cpu().numpy()
+        fx = m.process_fixed(x).cpu().numpy()
+    nf = fl.shape[0]
+    assert nf == 56469 and fx.shape == fl.shape
+    last = nf - 5                                    # the zero-padded tail does not repeat
+    # frame 0 has history 0, every later period starts with history = last sample of the period
+    assert np.array_equal(fl[q + 1:last - q], fl[2 * q + 1:last])
+    assert np.array_equal(fx[q + 1:last - q], fx[2 * q + 1:last])
+    assert np.array_equal(fl[1:q], fl[q + 1:2 * q]) and np.array_equal(fx[1:q], fx[q + 1:2 * q])
+    two = pcm[:170 * (2 * q) + 512]
+    ref_fl = mf.mfcc_float_ref(two)[q:2 * q]
+    e_max, e_l2 = _err(fl[q:2 * q], ref_fl)
+    assert e_max <= TOL and e_l2 <= TOL
+    ref_fx = mx.mfcc_fixed_ref(two, nceptrums=13, pad_mode="notebook")[q:2 * q]
+    assert np.array_equal(fx[q:2 * q], ref_fx)
+
+
 # ----------------------------------------------------------------------------- fixed
 
 def test_fixed_bit_exact_golden_wav(mfcc_amd, wav_pcm):
