@@ -144,6 +144,24 @@ int  mfcc_hip_process_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n
                                 size_t *n_frames);
 
 /*
+ * Ragged batch (host buffers): n_utterances utterances of different lengths in one launch -- the
+ * batched form of the driver's directory walk (show_dir_content -> mfcc_convert per file,
+ * software/main.c:206-247), every utterance an independent stream starting from reset.
+ * pcm: the utterances back to back; utterance u is pcm[offsets[u] .. offsets[u + 1]), offsets has
+ * n_utterances + 1 entries.  out: the frames of all utterances back to back, [sum frames][n_cep];
+ * utterance u's frames are rows frame_offsets[u] .. frame_offsets[u + 1] (n_utterances + 1 entries,
+ * written even when out is too small, so a caller can size out from a first call with capacity 0:
+ * MFCC_HIP_ERROR_BUFFER_SMALL).  Results are bit-identical to one mfcc_hip_process_* call per
+ * utterance.  Synchronous.
+ */
+int  mfcc_hip_process_ragged_i16(mfcc_hip_handle *h, const int16_t *pcm, const size_t *offsets,
+                                 size_t n_utterances, float *out, size_t out_capacity,
+                                 size_t *frame_offsets);
+int  mfcc_hip_process_ragged_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, const size_t *offsets,
+                                       size_t n_utterances, int16_t *out, size_t out_capacity,
+                                       size_t *frame_offsets);
+
+/*
  * Device-resident buffers (HBM in, HBM out), asynchronous on the handle's stream.
  * d_pcm:  channel c starts at d_pcm + c * ch_stride_samples (int16 units).
  * halo:   0 or 1.  1 = the first sample of every channel is only pre-emphasis history
@@ -178,6 +196,12 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed);
  * coefficients truncated to int16 like software/lift.py:39).  *n_frames_out may be NULL. */
 int  mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfcc_out,
                           int fixed, size_t *n_frames_out);
+
+/* The same for n_files files at once -- the whole directory walk of show_dir_content (main.c:206-247)
+ * as ONE ragged launch; every file is an independent stream, the files written are byte-identical to
+ * n_files calls of mfcc_hip_convert_wav.  n_frames_each (n_files entries) may be NULL. */
+int  mfcc_hip_convert_wavs(mfcc_hip_handle *h, const char *const *wav_in, const char *const *mfcc_out,
+                           size_t n_files, int fixed, size_t *n_frames_each);
 
 /* ---- serial wire format of the FPGA's coefficient stream (host only, no GPU) ---------------
  * mfcc/misc/magic.py:9-41 (MagicInserter: 0xa55a in front of every frame's coefficients),

@@ -203,6 +203,26 @@ class MFCC:
             raise ValueError("halo is only available on the device path")
         return self._host(pcm, True)
 
+    def process_batch(self, utterances, fixed=False):
+        """Many utterances of different lengths in ONE launch (the batched form of the driver's directory
+        walk, main.c:206-247).  ``utterances``: sequence of 1-D int16 arrays.  Returns a list of
+        ``(frames_u, nceptrums)`` arrays (views of one result buffer), bit-identical to calling
+        ``process`` / ``process_fixed`` on each utterance."""
+        utts = [np.ascontiguousarray(u, dtype=np.int16).reshape(-1) for u in utterances]
+        n = len(utts)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            offsets[1:] = np.cumsum([u.size for u in utts], dtype=np.uint64)
+        flat = np.concatenate(utts) if n and int(offsets[-1]) else np.zeros(0, dtype=np.int16)
+        fo = np.zeros(n + 1, dtype=np.uint64)
+        nf = sum(self.num_frames(u.size) for u in utts)
+        out = np.empty((nf, self.nceptrums), dtype=np.int16 if fixed else np.float32)
+        fn = self._lib.mfcc_hip_process_ragged_fixed_i16 if fixed else self._lib.mfcc_hip_process_ragged_i16
+        _lib.check(fn(self._h, flat.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n,
+                      out.ctypes.data_as(C.c_void_p), out.size, fo.ctypes.data_as(C.c_void_p)), "process_ragged")
+        assert int(fo[-1]) == nf
+        return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
+
     def time_launches(self, pcm, out, fixed=False, warmup=2, iters=10) -> float:
         """Average kernel time in ms over ``iters`` launches, HIP events on the launch stream."""
         import torch
@@ -216,6 +236,16 @@ class MFCC:
         return float(ms.value)
 
     # -- file level: mfcc_convert(sess, path_in, path_out), software/main.c:100-177 -----
+    def convert_many(self, paths_in, paths_out, fixed=True):
+        """``mfcc_convert`` for many files in one ragged launch; returns the frame count of each file."""
+        n = len(paths_in)
+        assert n == len(paths_out)
+        a_in = (C.c_char_p * n)(*[os.fsencode(p) for p in paths_in])
+        a_out = (C.c_char_p * n)(*[os.fsencode(p) for p in paths_out])
+        nf = (C.c_size_t * n)()
+        _lib.check(self._lib.mfcc_hip_convert_wavs(self._h, a_in, a_out, n, int(fixed), nf), "convert_wavs")
+        return [int(v) for v in nf]
+
     def convert(self, path_in, path_out, fixed=True) -> int:
         """``x.wav -> x.mfcc``: raw int16 LE ``[frame][nceptrums]``.  Returns the frame count."""
         nf = C.c_size_t(0)
@@ -245,18 +275,25 @@ def mfcc_close(sess: MFCC) -> None:
     sess.close()
 
 
-def show_dir_content(sess: MFCC, path, fixed=True):
-    """Recursive ``*.wav -> *.mfcc`` walk of ``show_dir_content`` (main.c:206-247).
+def show_dir_content(sess: MFCC, path, fixed=True, batch_bytes=1 << 30):
+    """Recursive ``*.wav -> *.mfcc`` walk of ``show_dir_content`` (main.c:206-247).  The files are
+    converted in ragged batches -- one launch per ``batch_bytes`` of WAV data instead of one USB
+    ping-pong per frame -- and the ``.mfcc`` files are byte-identical to per-file ``mfcc_convert``.
     Returns the list of (wav, mfcc) pairs converted."""
-    done = []
+    pairs = []
     for root, _dirs, files in os.walk(path):
         for name in sorted(files):
             if name.endswith(".wav"):
                 src = os.path.join(root, name)
-                dst = src[:-3] + "mfcc"
-                mfcc_convert(sess, src, dst, fixed=fixed)
-                done.append((src, dst))
-    return done
+                pairs.append((src, src[:-3] + "mfcc"))
+    batch, size = [], 0
+    for i, (src, dst) in enumerate(pairs):
+        batch.append((src, dst))
+        size += os.path.getsize(src)
+        if size >= batch_bytes or i == len(pairs) - 1:
+            sess.convert_many([b[0] for b in batch], [b[1] for b in batch], fixed=fixed)
+            batch, size = [], 0
+    return pairs
 
 
 def lifter(cepstra, L=22):

@@ -258,12 +258,13 @@ bool use_fused(const mfcc_hip_handle *h) {
 }
 
 int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t stride, size_t nch,
-           int halo, void *d_out, size_t *n_frames) {
+           int halo, void *d_out, size_t *n_frames, size_t force_frames = 0) {
     if (!h || (!d_pcm && n * nch) || halo < 0 || halo > 1) return MFCC_HIP_ERROR_INVALID_PARAM;
     if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
     if (!fixed && h->r.float_impl == MFCC_HIP_IMPL_FUSED512 && !h->fused_ok)
         return MFCC_HIP_ERROR_UNSUPPORTED;
-    const size_t nf = count_frames(h->r, n);
+    // force_frames: the packed stream of the ragged entry points -- every hop position is a frame
+    const size_t nf = force_frames ? force_frames : count_frames(h->r, n);
     if (n_frames) *n_frames = nf;
     if (nf == 0 || nch == 0) return MFCC_HIP_SUCCESS;
     if (!d_out) return MFCC_HIP_ERROR_INVALID_PARAM;
@@ -352,6 +353,80 @@ int process_host(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, size_t n, s
     rc = launch(h, fixed, h->d_in, n, n, nch, 0, h->d_out, nullptr);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, h->d_out, n_out * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MFCC_HIP_SUCCESS;
+}
+
+// ---- ragged batch: many utterances of different lengths, one launch.
+// The utterances are packed into ONE stream at offsets that are multiples of the hop, separated by
+// zeros: at least one zero in front (pre-emphasis history 0, like after the driver's soft reset,
+// main.c:21-34) and zeros behind up to the end of the last frame (the zero-padded tail of main.c:134-144).
+// Frame k of utterance u is then frame start_u / hop + k of the packed stream -- the same samples, the
+// same arithmetic, bit for bit -- and the frames that fall into the gaps are simply not copied out.
+template <typename OutT>
+__global__ void gather_rows_kernel(const OutT *__restrict__ src, OutT *__restrict__ dst,
+                                   const long long *__restrict__ desc, long long n_utt, int row) {
+    for (long long u = blockIdx.x; u < n_utt; u += gridDim.x) {
+        const long long s0 = desc[3 * u] * row, d0 = desc[3 * u + 1] * row, n = desc[3 * u + 2] * row;
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = src[s0 + i];
+    }
+}
+
+template <typename OutT>
+int process_ragged(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, const size_t *offsets, size_t n_utt,
+                   OutT *out, size_t cap, size_t *frame_offsets) {
+    if (!h || !offsets || !frame_offsets) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
+    const size_t hop = size_t(h->r.hop), nfft = size_t(h->r.nfft), ncep = size_t(h->r.n_cep);
+    std::vector<long long> desc(3 * n_utt);                 // (first packed frame, first output frame, frames)
+    std::vector<size_t> start(n_utt);
+    size_t pos = 0, total = 0;
+    frame_offsets[0] = 0;
+    for (size_t u = 0; u < n_utt; ++u) {
+        if (offsets[u + 1] < offsets[u]) return MFCC_HIP_ERROR_INVALID_PARAM;
+        const size_t n = offsets[u + 1] - offsets[u];
+        if (n && !pcm) return MFCC_HIP_ERROR_INVALID_PARAM;
+        const size_t nf = count_frames(h->r, n);
+        start[u] = pos;
+        desc[3 * u] = (long long)(pos / hop);
+        desc[3 * u + 1] = (long long)total;
+        desc[3 * u + 2] = (long long)nf;
+        total += nf;
+        frame_offsets[u + 1] = total;
+        if (nf) {
+            const size_t extent = std::max(n, hop * (nf - 1) + nfft);
+            pos = (pos + extent + 1 + hop - 1) / hop * hop;
+        }
+    }
+    if (total == 0) return MFCC_HIP_SUCCESS;
+    if (!out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    const size_t F = pos / hop;                              // frames of the packed stream
+    const size_t len = pos + nfft + hop;                     // its samples (zeros behind the last utterance)
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
+    if (rc) return rc;
+    rc = ensure(h, &h->d_out, &h->d_out_bytes, (F + total) * ncep * sizeof(OutT) + desc.size() * sizeof(long long) + 64);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_in, 0, len * sizeof(int16_t), h->stream));
+    for (size_t u = 0; u < n_utt; ++u) {
+        const size_t n = offsets[u + 1] - offsets[u];
+        if (desc[3 * u + 2] && n)
+            HIP_TRY(h, hipMemcpyAsync(static_cast<int16_t *>(h->d_in) + start[u], pcm + offsets[u], n * sizeof(int16_t),
+                                      hipMemcpyHostToDevice, h->stream));
+    }
+    OutT *d_all = static_cast<OutT *>(h->d_out);
+    OutT *d_dense = d_all + F * ncep;
+    // 8-byte aligned descriptor table behind the two output buffers
+    size_t desc_off = ((F + total) * ncep * sizeof(OutT) + 7) & ~size_t(7);
+    long long *d_desc = reinterpret_cast<long long *>(static_cast<char *>(h->d_out) + desc_off);
+    HIP_TRY(h, hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, fixed, h->d_in, len, len, 1, 0, d_all, nullptr, F);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>(n_utt, size_t(h->n_cu) * 8);
+    hipLaunchKernelGGL(gather_rows_kernel<OutT>, dim3(blocks), dim3(256), 0, h->stream, d_all, d_dense, d_desc,
+                       (long long)n_utt, (int)ncep);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, d_dense, total * ncep * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MFCC_HIP_SUCCESS;
 }
@@ -586,6 +661,16 @@ int mfcc_hip_process_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, size_t n,
     return process_host<int16_t>(h, true, pcm, n, nch, out, cap, n_frames);
 }
 
+int mfcc_hip_process_ragged_i16(mfcc_hip_handle *h, const int16_t *pcm, const size_t *offsets, size_t n_utt,
+                                float *out, size_t cap, size_t *frame_offsets) {
+    return process_ragged<float>(h, false, pcm, offsets, n_utt, out, cap, frame_offsets);
+}
+
+int mfcc_hip_process_ragged_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, const size_t *offsets, size_t n_utt,
+                                      int16_t *out, size_t cap, size_t *frame_offsets) {
+    return process_ragged<int16_t>(h, true, pcm, offsets, n_utt, out, cap, frame_offsets);
+}
+
 int mfcc_hip_process_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t n, size_t stride, size_t nch,
                              int halo, void *d_out, size_t *n_frames) {
     return launch(h, false, d_pcm, n, stride, nch, halo, d_out, n_frames);
@@ -658,6 +743,54 @@ int mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mfc
     std::fclose(o);
     if (wr != cep.size()) return MFCC_HIP_ERROR_IO;
     if (n_frames_out) *n_frames_out = nf;
+    return MFCC_HIP_SUCCESS;
+}
+
+// float coefficients -> the int16 a `.mfcc` file holds: astype(np.int16) of software/lift.py:39 (truncate)
+static inline int16_t to_mfcc_i16(float v) {
+    if (!(v == v)) v = 0.0f;
+    if (v > 32767.0f) v = 32767.0f;
+    if (v < -32768.0f) v = -32768.0f;
+    return int16_t(v);
+}
+
+int mfcc_hip_convert_wavs(mfcc_hip_handle *h, const char *const *wav_in, const char *const *mfcc_out, size_t n_files,
+                          int fixed, size_t *n_frames_each) {
+    if (!h || (n_files && (!wav_in || !mfcc_out))) return MFCC_HIP_ERROR_INVALID_PARAM;
+    std::vector<int16_t> pcm;
+    std::vector<size_t> off(n_files + 1, 0), fo(n_files + 1, 0);
+    for (size_t i = 0; i < n_files; ++i) {
+        if (!wav_in[i] || !mfcc_out[i]) return MFCC_HIP_ERROR_INVALID_PARAM;
+        std::vector<int16_t> one;
+        int rc = read_wav_i16(wav_in[i], h->r.sample_rate, one);
+        if (rc) return rc;
+        pcm.insert(pcm.end(), one.begin(), one.end());
+        off[i + 1] = pcm.size();
+    }
+    size_t total = 0;
+    for (size_t i = 0; i < n_files; ++i) total += count_frames(h->r, off[i + 1] - off[i]);
+    const size_t ncep = size_t(h->r.n_cep);
+    std::vector<int16_t> cep(total * ncep);
+    int rc;
+    if (fixed) {
+        rc = mfcc_hip_process_ragged_fixed_i16(h, pcm.data(), off.data(), n_files, cep.data(), cep.size(), fo.data());
+        if (rc) return rc;
+    } else {
+        std::vector<float> f(cep.size());
+        rc = mfcc_hip_process_ragged_i16(h, pcm.data(), off.data(), n_files, f.data(), f.size(), fo.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < f.size(); ++i) cep[i] = to_mfcc_i16(f[i]);
+    }
+    for (size_t i = 0; i < n_files; ++i) {
+        const size_t nf = fo[i + 1] - fo[i];
+        FILE *o = std::fopen(mfcc_out[i], "wb");
+        if (!o) return MFCC_HIP_ERROR_IO;
+        const size_t want = nf * ncep;
+        const size_t wr = want ? std::fwrite(cep.data() + fo[i] * ncep, sizeof(int16_t), want, o) : 0;
+        std::fclose(o);
+        if (wr != want) return MFCC_HIP_ERROR_IO;
+        if (n_frames_each) n_frames_each[i] = nf;
+    }
     return MFCC_HIP_SUCCESS;
 }
 

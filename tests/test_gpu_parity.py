@@ -299,3 +299,63 @@ def test_convert_wav_to_mfcc_file(mfcc_amd, golden_dir, tmp_path, wav_pcm):
         assert mfcc_amd.mfcc_convert(sess, os.path.join(golden_dir, "f2bjrop1.0.wav"), str(out)) == 0
     raw = np.fromfile(out, dtype="<i2").reshape(-1, 32)               # view.py:24-25 / lift.py:35-36
     assert np.array_equal(raw, mx.mfcc_fixed_ref(wav_pcm, nceptrums=32))
+
+
+def test_directory_walk_in_one_launch_writes_the_same_files(mfcc_amd, golden_dir, tmp_path, wav_pcm):
+    """show_dir_content (main.c:206-247) as ragged batches: byte-identical .mfcc files to per-file conversion."""
+    import shutil
+    import wave
+    d = tmp_path / "corpus" / "sub"
+    d.mkdir(parents=True)
+    shutil.copy(os.path.join(golden_dir, "f2bjrop1.0.wav"), d / "a.wav")
+    rng = np.random.default_rng(8)
+    for name, n in (("b.wav", 700), ("c.wav", 40000), ("d.wav", 300)):
+        with wave.open(str(d.parent / name), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(rng.integers(-20000, 20000, size=n, dtype=np.int16).astype("<i2").tobytes())
+    with mfcc_amd.mfcc_open() as sess:
+        pairs = mfcc_amd.show_dir_content(sess, str(tmp_path / "corpus"))
+        assert len(pairs) == 4
+        for src, dst in pairs:
+            one = str(tmp_path / "single.mfcc")
+            assert mfcc_amd.mfcc_convert(sess, src, one) == 0
+            assert open(dst, "rb").read() == open(one, "rb").read(), src
+    raw = np.fromfile(d / "a.mfcc", dtype="<i2").reshape(-1, 32)
+    assert np.array_equal(raw, mx.mfcc_fixed_ref(wav_pcm, nceptrums=32))
+
+
+# ----------------------------------------------------------------------------- ragged batch
+
+@pytest.mark.parametrize("pad_mode", ["notebook", "stream"])
+def test_ragged_batch_is_bit_identical_to_per_utterance_calls(mfcc_amd, pad_mode, wav_pcm):
+    """One launch over utterances of different lengths (packed at hop-multiple offsets with zero gaps)
+    reproduces the per-utterance results bit for bit, float and fixed; too-short and empty utterances
+    included; the golden wav among them is checked against the oracles."""
+    rng = np.random.default_rng(12)
+    lens = [0, 100, 511, 512, 513, 681, 682, 683, 5000, 170 * 37 + 512, 23456, 1, 170 * 200 + 512 + 169]
+    utts = [rng.integers(-32768, 32767, size=n, dtype=np.int16) for n in lens] + [wav_pcm]
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode=pad_mode) as m:
+        fl = m.process_batch(utts)
+        fx = m.process_batch(utts, fixed=True)
+        assert len(fl) == len(fx) == len(utts)
+        for u, a, b in zip(utts, fl, fx):
+            ra, rb = m.process(u), m.process_fixed(u)
+            assert a.shape == ra.shape and b.shape == rb.shape
+            assert np.array_equal(a, ra, equal_nan=True), len(u)
+            assert np.array_equal(b, rb), len(u)
+        assert m.process_batch([]) == []
+    ref = mf.mfcc_float_ref(wav_pcm, pad_mode=pad_mode)
+    e_max, e_l2 = _err(fl[-1], ref)
+    assert e_max <= TOL and e_l2 <= TOL
+    assert np.array_equal(fx[-1], mx.mfcc_fixed_ref(wav_pcm, nceptrums=13, pad_mode=pad_mode))
+
+
+def test_ragged_batch_many_short_utterances(mfcc_amd):
+    """Config-5 shape at a reduced count: 300 utterances of 10 s in one launch."""
+    rng = np.random.default_rng(5)
+    utts = [(rng.standard_normal(160000) * 3000).clip(-32768, 32767).astype(np.int16) for _ in range(300)]
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13) as m:
+        got = m.process_batch(utts)
+        for i in (0, 17, 299):
+            assert got[i].shape == (m.num_frames(160000), 13) == (939, 13)
+            assert np.array_equal(got[i], m.process(utts[i]))
