@@ -139,6 +139,11 @@ class Gen:
         return self._asm("v_pk_fma_f32", [("v", d.name), ("s", k2), ("v", m.name)], g * d.num,
                          op_sel=[1, 0, 0], op_sel_hi=[0, 1, 1], neg_lo=[0, nl2, 0], neg_hi=[0, nh2, 0])
 
+    def mul_mi(self, d):             # (-i) d = (di, -dr): 1 op
+        k, _, _ = self.const(1.0, 1.0)
+        return self._asm("v_pk_mul_f32", [("v", d.name), ("s", k)], -1j * d.num, op_sel=[1, 0], op_sel_hi=[0, 1],
+                         neg_hi=[0, 1])
+
     def mulv(self, x, tw, twnum, conj=False):
         """x * tw (or conj(x) * tw) for a per-lane complex variable tw = (c, s): 2 ops"""
         m = self._asm("v_pk_mul_f32", [("v", x.name), ("v", tw)], x.num.real * twnum, op_sel=[0, 0], op_sel_hi=[0, 1],
@@ -241,6 +246,42 @@ def gen_cfft16():
     return src, G.ops
 
 
+def gen_cfft32_half(h):
+    """Half of a complex 32-point DFT by one decimation-in-frequency step: outputs F[2m + h], m = 0..15, of
+    the 32 inputs xl[n] = x[n], xh[n] = x[n + 16]:  a[n] = xl[n] + xh[n] (h = 0) or
+    (xl[n] - xh[n]) W32^n (h = 1), then the 16-point DFT of a."""
+    rng = np.random.default_rng(3 + h)
+    x = rng.standard_normal(32) + 1j * rng.standard_normal(32)
+    G = Gen()
+    xl = [CV("xl[%d]" % i, x[i]) for i in range(16)]
+    xh = [CV("xh[%d]" % i, x[i + 16]) for i in range(16)]
+    a = []
+    for n in range(16):
+        if h == 0:
+            a.append(G.add(xl[n], xh[n]))
+        else:
+            d = G.sub(xl[n], xh[n])
+            if n == 0:
+                a.append(d)
+            elif n == 8:
+                a.append(G.mul_mi(d))
+            else:
+                a.append(G.mulc(d, cmath.exp(-2j * math.pi * n / 32)))
+    X = fft_dit(G, a, lambda p, q: (G.add(p, q), G.sub(p, q)))
+    ref = np.fft.fft(x)[h::2]
+    err = max(abs(v.num - r) for v, r in zip(X, ref)) / np.abs(ref).max()
+    assert err < 1e-12, err
+    lines, tight = schedule(G.lines)
+    print("cfft32_h%d: %d dependences closer than %d slots" % (h, tight, ISSUE_DISTANCE))
+    body = emit_consts(G) + "\n" + "\n".join(lines) + "\n" + \
+        "\n".join("    z[%d] = %s;" % (k, v.name) for k, v in enumerate(X))
+    src = ("// outputs F[2m + %d], m = 0..15, of the complex 32-point DFT of x[n] = xl[n], x[n + 16] = xh[n]\n"
+           "// (one decimation-in-frequency step, then a 16-point DFT): %d packed VALU ops\n"
+           "__device__ __forceinline__ void cfft32_h%d(const v2f (&xl)[16], const v2f (&xh)[16], v2f (&z)[16]) {\n%s\n}\n"
+           % (h, G.ops, h, body))
+    return src, G.ops
+
+
 def gen_rfft32_tw():
     rng = np.random.default_rng(1)
     e = rng.standard_normal(32) * 1000
@@ -311,14 +352,17 @@ def gen_rfft32_tw():
 def main():
     a, na = gen_rfft32_tw()
     b, nb = gen_cfft16()
+    c0, n0 = gen_cfft32_half(0)
+    c1, n1 = gen_cfft32_half(1)
     out = ("// GENERATED by gen_codelets.py -- do not edit.  Packed-fp32 straight-line FFT codelets (see the\n"
            "// generator's docstring); every op was traced numerically against numpy.fft.\n"
            "#pragma once\n#include <hip/hip_runtime.h>\n\nnamespace mfcc_codelets {\n\n"
-           "typedef float v2f __attribute__((ext_vector_type(2)));\n\n" + a + "\n" + b + "\n}  // namespace mfcc_codelets\n")
+           "typedef float v2f __attribute__((ext_vector_type(2)));\n\n" + a + "\n" + b + "\n" + c0 + "\n" + c1 +
+           "\n}  // namespace mfcc_codelets\n")
     path = os.path.join(HERE, "codelets_gen.hpp")
     with open(path, "w") as f:
         f.write(out)
-    print("rfft32_tw: %d packed ops, cfft16: %d packed ops -> %s" % (na, nb, path))
+    print("rfft32_tw: %d packed ops, cfft16: %d, cfft32_h0: %d, cfft32_h1: %d -> %s" % (na, nb, n0, n1, path))
 
 
 if __name__ == "__main__":

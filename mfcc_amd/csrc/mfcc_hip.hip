@@ -16,6 +16,7 @@
 #include "../../include/mfcc_hip.h"
 #include "kernels_generic.hpp"
 #include "kernel_fixed512.hpp"
+#include "kernel_fused1024.hpp"
 #include "kernel_fused512.hpp"
 #include "tables.hpp"
 
@@ -108,6 +109,7 @@ struct mfcc_hip_handle {
     int n_cu = 0;
     bool fixed_ok = false;
     bool fused_ok = false;
+    bool fused1k_ok = false;      // the fused 1024/341/40 float kernel covers this handle's parameters
     bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
     void *arena = nullptr;
@@ -115,6 +117,7 @@ struct mfcc_hip_handle {
     mfcc_k::FixedTables xt{};
     mfcc_fused::FusedTables fu{};
     mfcc_fixed512::Tables x5{};
+    mfcc_fused1024::Tables f1k{};
     // scratch for the host-buffer entry points
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -210,6 +213,11 @@ int build_tables(mfcc_hip_handle *h) {
                   mfcc_fused::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
     size_t o_fu = 0;
     if (h->fused_ok) o_fu = a.put(fused_blob);
+    std::vector<char> f1k_blob;
+    h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
+                    mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob);
+    size_t o_f1k = 0;
+    if (h->fused1k_ok) o_f1k = a.put(f1k_blob);
 
     HIP_TRY(h, hipMalloc(&h->arena, a.host.size() + 256));
     HIP_TRY(h, hipMemcpy(h->arena, a.host.data(), a.host.size(), hipMemcpyHostToDevice));
@@ -240,6 +248,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.n_cep = r.n_cep;
     }
     if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fu);
+    if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
         h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];
@@ -294,6 +303,9 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
     } else if (use_fused(h)) {
         if (!mfcc_fused::launch(s, h->fu, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
+    } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
+               mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) {
+        // fused 1024/341/40 kernel launched
     } else {
         long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
         long long cap = (long long)h->n_cu * 8;
@@ -711,6 +723,7 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return mfcc_fused::kernel_name();
+    if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_fused1024::kernel_name();
     return "mfcc_float_generic_kernel";
 }
 

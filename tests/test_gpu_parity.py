@@ -179,6 +179,79 @@ def test_float_config4_1024_40(mfcc_amd):
     assert e_max <= TOL and e_l2 <= TOL
 
 
+def test_fused1024_kernel_alignment_shifts_and_edges(mfcc_amd):
+    """Config-4 parameters (1024 / 341 / 40 mel, power scale = nfft) on the fused 1024 kernel: every
+    alignment shift of the window fetch (odd hop: the shift changes from tile to tile too), misaligned
+    channel strides, a history halo, stream ends, ragged tile counts -- against the generic kernel and,
+    on one channel, the oracle."""
+    import torch
+    nfr = 16 * 19 + 7
+    n = 341 * (nfr - 1) + 1024
+    nch = 5
+    rng = np.random.default_rng(41)
+    kw = dict(nfft=1024, nfilters=40, nceptrums=13, power_scale=0)
+    for base_off in range(8):
+        stride = n + 5 + base_off
+        flat = torch.from_numpy(rng.integers(-32768, 32767, size=base_off + stride * nch + 64,
+                                             dtype=np.int16)).cuda()
+        view = torch.as_strided(flat, (nch, n), (stride, 1), storage_offset=base_off)
+        for halo in (0, 1):
+            with mfcc_amd.MFCC(**kw) as mfu, mfcc_amd.MFCC(impl="generic", **kw) as mge:
+                assert mfu.kernel_name().endswith("fused1024_kernel") and mfu.hop == 341
+                assert mge.kernel_name().endswith("generic_kernel")
+                a = mfu.process(view, halo=halo).cpu().numpy()
+                b = mge.process(view, halo=halo).cpu().numpy()
+            assert a.shape == b.shape == (nch, (n - halo - 1024) // 341 + 1, 13)
+            assert np.isfinite(a).all()
+            e_max, e_l2 = _err(a, b)
+            assert e_max <= 2e-5 and e_l2 <= 2e-5, (base_off, halo, e_max, e_l2)
+            if halo == 0:
+                a0 = a
+    ref = mf.mfcc_float_ref(view[2].cpu().numpy(), nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
+    e_max, e_l2 = _err(a0[2], ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
+@pytest.mark.parametrize("ncep", [1, 13, 16])
+def test_fused1024_other_ncep_stream_padding_and_lifter(mfcc_amd, ncep):
+    pcm = np.stack([mf.synth_pcm(341 * 40 + 1024 + 55, seed=300 + s) for s in range(3)])
+    ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream", nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
+    with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=ncep, power_scale=0, pad_mode="stream") as m:
+        assert m.kernel_name().endswith("fused1024_kernel")
+        got = m.process(pcm)
+        many = m.process_batch([pcm[0], pcm[1][:5000], pcm[2][:1023]])
+        assert np.array_equal(many[0], got[0]) and many[2].shape == (1, ncep)
+    assert got.shape == ref.shape
+    e_max, e_l2 = _err(got, ref)
+    assert e_max <= TOL and e_l2 <= TOL
+    if ncep == 16:
+        with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=16, power_scale=0, pad_mode="stream", lifter=22.0) as m:
+            lif = m.process(pcm)
+        e_max, e_l2 = _err(lif, np.stack([mf.lifter(r, 22) for r in ref]))
+        assert e_max <= TOL and e_l2 <= TOL
+
+
+def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
+    """Config 4 at 1 h x 4 channels of speech-like audio: frames repeat bit for bit with the period of the
+    tiled input (341 q samples), one period checked against the oracle."""
+    import torch
+    q = 400
+    period = wav_pcm[:341 * q]
+    n = 16000 * 3600
+    pcm = np.tile(period, n // len(period) + 1)[:n]
+    x = torch.from_numpy(np.stack([pcm, pcm[::-1].copy(), pcm // 2, pcm])).cuda()
+    with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=13, power_scale=0) as m:
+        out = m.process(x)
+        a = out[0].cpu().numpy()
+        assert torch.equal(out[0], out[3])
+    nf = a.shape[0]
+    assert nf == (n - 1024) // 341 + 1 == 168912
+    assert np.array_equal(a[q + 1:nf - q], a[2 * q + 1:nf])
+    ref = mf.mfcc_float_ref(pcm[:341 * (2 * q) + 1024], nfft=1024, hop=341, n_mel=40, power_scale=1024.0)[q:2 * q]
+    e_max, e_l2 = _err(a[q:2 * q], ref)
+    assert e_max <= TOL and e_l2 <= TOL
+
+
 def test_float_linearity_property_full_size(mfcc_amd):
     """Size-independent property at config-2 size (10 min): scaling the input by 2 adds
     exactly 2*sqrt(32) to c0 (log2 of 4x power through the ortho DCT) and leaves c1.. unchanged."""
