@@ -119,7 +119,7 @@ def main():
 
     # HBM bytes per launch of this kernel, from the committed rocprofv3 PMC summary of the same
     # command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; profiles/summarize_rocprof.py)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_per_frame = None, None, None
     try:
         import glob
         for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
@@ -129,6 +129,7 @@ def main():
                     d.get("frames_per_launch") == frames and "hbm_traffic_bytes_per_launch" in d:
                 traffic = round(d["hbm_traffic_bytes_per_launch"])
                 traffic_src = os.path.relpath(pj, ROOT)
+                valu_per_frame = d.get("valu_wave_instructions_per_frame")
                 break
     except Exception:
         traffic = None
@@ -218,6 +219,16 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if valu_per_frame:
+            # the binding limit: every VALU wave-instruction holds a SIMD for >= 4 clocks
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            ceiling = n_cu * 4 * 2.4e9 / (valu_per_frame * 4.0)
+            rate = frames / (kernel_ms * 1e-3)
+            line["valu_roofline"] = {
+                "bound": "valu", "achieved": round(rate, 1), "peak": round(ceiling, 1), "unit": "frames/s per GPU",
+                "frac": round(rate / ceiling, 4),
+                "note": "peak = CUs x 4 SIMDs x 2.4 GHz / (%.1f VALU wave-instructions per frame x 4 clocks), "
+                        "instruction count from %s" % (valu_per_frame, traffic_src)}
         if pcie:
             line["pcie_inclusive"] = pcie
         print(json.dumps(line))
