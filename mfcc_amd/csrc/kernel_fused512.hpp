@@ -1,6 +1,6 @@
 // Fused 512/170/32 float kernel for gfx950 (MI355X): the whole chain of mfcc/core --
 // pre-emphasis -> 512-sample frames (hop 170) -> Hamming -> FFT -> |.|^2 -> 32 mel -> log2 ->
-// DCT-II -> first n_cep (<= 16) -- in one launch.
+// DCT-II -> first n_cep (<= 32: the driver and the notebook keep all 32) -- in one launch.
 //
 // Work unit: a workgroup of 4 waves owns a tile of 16 consecutive frames (the N dimension of
 // v_mfma_f32_16x16x4_f32).  Per tile:
@@ -49,7 +49,7 @@
 
 namespace mfcc_fused {
 
-constexpr int kNfft = 512, kHop = 170, kMel = 32, kMaxCep = 16;
+constexpr int kNfft = 512, kHop = 170, kMel = 32, kMaxCep = 32;   // 32 = all of them (main.c:13, notebook cell 39)
 constexpr int kTile = 16;                 // frames per workgroup tile (MFMA N dimension)
 constexpr int kWaves = 4;
 constexpr int kTileHop = kTile * kHop;    // 2720 samples between consecutive tiles
@@ -60,7 +60,8 @@ constexpr int kTFrame = 16 * kTRow + 2;   // 546 words per frame (== 2 mod 32): 
                                           // conflict on every one of them (SQ_LDS_BANK_CONFLICT)
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
 constexpr int kAmel = 17;                 // mel A operands per wave: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
-constexpr int kAextra = 8;                // role operands: role 0 DCT (8); role 1 column-16 DFT (4) + its mel (4)
+constexpr int kAextra = 16;               // role operands: role 0 DCT (8 + 8 for coefficients 16..31); role 1
+                                          // column-16 DFT (4) + its mel (4)
 constexpr int kFetchers = 192;            // threads that fetch and park the sample window: roles 1..3
 constexpr int kSUsed = 2 * 8 * kFetchers; // 3072 fp32 slots of the window (7 + 15 * 170 + 512 = 3069 are read)
 constexpr int kQWords = kWaves * 2 * 256;  // partial mel sums: [wave][block][lane*4]
@@ -127,14 +128,15 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) mel_op(wv, idx++, 1, k2);
         if (idx != kAmel) return false;
     }
-    // role 0 -- DCT rows: lane (coeff = l&15, g = l>>4) holds D[coeff][16 blk + 4 g + r]
+    // role 0 -- DCT rows: lane (coeff = l&15, g = l>>4) holds D[16 half + coeff][16 blk + 4 g + r]
     std::vector<double> dd = dct_rows(n_cep, kMel, lifter);                    // [n_cep][32]
-    for (int blk = 0; blk < 2; ++blk)
-        for (int r = 0; r < 4; ++r)
-            for (int l = 0; l < 64; ++l) {
-                int coeff = l & 15, filt = 16 * blk + 4 * (l >> 4) + r;
-                E(0, 4 * blk + r, l) = coeff < n_cep ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
-            }
+    for (int half = 0; half < 2; ++half)
+        for (int blk = 0; blk < 2; ++blk)
+            for (int r = 0; r < 4; ++r)
+                for (int l = 0; l < 64; ++l) {
+                    int coeff = 16 * half + (l & 15), filt = 16 * blk + 4 * (l >> 4) + r;
+                    E(0, 8 * half + 4 * blk + r, l) = coeff < n_cep ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
+                }
     // role 1 -- column 16: X[16 + 32 k2] = sum_n2 v[n2] W512^(n2 (16 + 32 k2)); MFMA row i = 4g + r:
     // r=0: Re k2=2g, r=1: Im k2=2g, r=2: Re k2=2g+1, r=3: Im k2=2g+1
     for (int t = 0; t < 4; ++t)
@@ -346,11 +348,24 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Fus
     // uniform part of the address on the scalar unit; lane_off = lo * n_cep + 4 q
     const long long fr0 = (long long)c.t_in * kTile;
     const long long rows_left = s.frames_per_ch - fr0;
+    float *o = out + ((long long)c.ch * s.frames_per_ch + fr0) * t.n_cep + lane_off;
     if (lo < rows_left) {
-        float *o = out + ((long long)c.ch * s.frames_per_ch + fr0) * t.n_cep + lane_off;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < t.n_cep) o[r] = d0[r] + d1[r];
+    }
+    if (t.n_cep > 16) {                        // coefficients 16..31: a second M tile (uniform branch)
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e0 = MFCC_MFMA(ax[8 + r], l0[r], e0);
+            e1 = MFCC_MFMA(ax[12 + r], l1[r], e1);
+        }
+        if (lo < rows_left) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 + 4 * q + r < t.n_cep) o[16 + r] = e0[r] + e1[r];
+        }
     }
 }
 

@@ -146,7 +146,7 @@ def test_fused_kernel_alignment_shifts_and_edges(mfcc_amd):
     assert e_max <= TOL and e_l2 <= TOL
 
 
-@pytest.mark.parametrize("ncep", [1, 4, 12, 16])
+@pytest.mark.parametrize("ncep", [1, 4, 12, 16, 17, 24, 32])
 def test_fused_kernel_other_ncep_and_stream_padding(mfcc_amd, ncep):
     pcm = np.stack([mf.synth_pcm(170 * 50 + 512 + 37, seed=200 + s) for s in range(3)])
     ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream")
