@@ -133,3 +133,52 @@ def test_lifter_helper_matches_reference_formula():
     c = np.random.default_rng(0).standard_normal((7, 32))
     np.testing.assert_allclose(mfcc_amd.lifter(c, 22), mf.lifter(c, 22))
     assert mfcc_amd.lifter(c, 0) is not None and np.array_equal(mfcc_amd.lifter(c, 0), c)
+
+
+def test_header_is_plain_c_and_the_integration_snippet_compiles(tmp_path):
+    """include/mfcc_hip.h must be usable from the reference's C driver: C99, no C++; the replacement
+    functions shown in INTEGRATION.md compile against it (syntax only: linking needs the GPU library)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "mfcc_hip.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                   check=True)
+    src = tmp_path / "driver.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include "mfcc_hip.h"
+#define NFFT 512
+#define STEPSIZE 170
+#define NCEPSTRUMS 32
+#define SAMPLERATE 16000
+struct mfcc_s { mfcc_hip_handle *h; };
+int mfcc_open(struct mfcc_s *sess) {
+    mfcc_hip_params p;
+    mfcc_hip_default_params(&p);
+    p.nfft = NFFT; p.hop = STEPSIZE; p.n_mel = 32; p.n_cep = NCEPSTRUMS; p.sample_rate = SAMPLERATE;
+    p.pad_mode = MFCC_HIP_PAD_STREAM;
+    int ret = mfcc_hip_create(&p, &sess->h);
+    if (ret) printf("Error mfcc_hip_create %d (%s)\n", ret, mfcc_hip_strerror(ret));
+    return ret;
+}
+int mfcc_convert(struct mfcc_s *sess, const char *in, const char *out) {
+    return mfcc_hip_convert_wav(sess->h, in, out, 1, NULL) ? -1 : 0;
+}
+int convert_dir(struct mfcc_s *sess, const char *const *in, const char *const *out, size_t n) {
+    return mfcc_hip_convert_wavs(sess->h, in, out, n, 1, NULL);
+}
+int ragged(struct mfcc_s *sess, const int16_t *pcm, const size_t *off, size_t n, int16_t *cep, size_t cap, size_t *fo) {
+    return mfcc_hip_process_ragged_fixed_i16(sess->h, pcm, off, n, cep, cap, fo);
+}
+int serial(const int16_t *cep, size_t nf, uint8_t *wire, size_t cap, long long *power) {
+    if (mfcc_hip_serial_pack(cep, nf, NCEPSTRUMS, wire, cap)) return -1;
+    return mfcc_hip_eval_power(cep, NCEPSTRUMS, (int)nf, 0, power);
+}
+void mfcc_close(struct mfcc_s *sess) { mfcc_hip_destroy(sess->h); }
+""")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                    str(src)], check=True)
