@@ -337,14 +337,10 @@ __device__ __forceinline__ void mel_log2(const float *Qt, int lane, f32x4 &l0, f
 // DCT-II (cells 38-39) and store: log-mel register r of block b == B[k = q][j = lo] of the DCT
 // product, so the mel accumulator layout feeds the DCT MFMAs without any lane movement.
 __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const FusedTables &t, const f32x4 &l0,
-                                          const f32x4 &l1, const float (&ax)[kAextra], const Cursor &c, int lo,
+                                          const f32x4 &l1, const f32x4 &d0, const f32x4 &d1,
+                                          const float (&ax)[kAextra], const Cursor &c, int lo,
                                           int q, int lane_off, float *__restrict__ out) {
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        d0 = MFCC_MFMA(ax[r], l0[r], d0);
-        d1 = MFCC_MFMA(ax[4 + r], l1[r], d1);
-    }
+    // d0 + d1 = coefficients 0..15 (their MFMAs are issued by the caller, interleaved with the mel MFMAs)
     // uniform part of the address on the scalar unit; lane_off = lo * n_cep + 4 q
     const long long fr0 = (long long)c.t_in * kTile;
     const long long rows_left = s.frames_per_ch - fr0;
@@ -490,13 +486,48 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
 
         // ---------------- MFMA window (frame column = lo, K index = q)
         f32x4 x0 = zero, y0 = zero, x1 = zero, y1 = zero;
-        if (role == 1) {
-            // column 16 -> bins 16 + 32 j of this tile, fed to both filter blocks from registers
-            // two chains of two: the K = 16 contraction has no other ILP
-            f32x4 sp = MFCC_MFMA(ax[0], Vt[lo * kVStride + 0 + q], zero);
-            f32x4 sp2 = MFCC_MFMA(ax[1], Vt[lo * kVStride + 4 + q], zero);
-            sp = MFCC_MFMA(ax[2], Vt[lo * kVStride + 8 + q], sp);
-            sp2 = MFCC_MFMA(ax[3], Vt[lo * kVStride + 12 + q], sp2);
+        if (role == 0) {
+            // this tile's mel MFMAs and the previous tile's DCT MFMAs (coefficients 0..15) in ONE basic block,
+            // interleaved: six independent accumulator chains instead of two long tails (lm = 0 before the
+            // first tile; only the store depends on have_prev)
+            f32x4 d0 = zero, d1 = zero;
+            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
+            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
+            d0 = MFCC_MFMA(ax[0], lm0[0], d0);
+            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
+            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
+            d1 = MFCC_MFMA(ax[4], lm1[0], d1);
+#pragma unroll
+            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
+                const int i = k2 - kB1_LO;
+                if (i & 1) y1 = MFCC_MFMA(am[4 + i], pw[k2], y1);
+                else x1 = MFCC_MFMA(am[4 + i], pw[k2], x1);
+                if (i >= 1 && i <= 6) {                       // six more DCT MFMAs, one every mel MFMA
+                    const int r = (i + 1) >> 1;               // 1,1,2,2,3,3
+                    if (i & 1) d0 = MFCC_MFMA(ax[r], lm0[r], d0);
+                    else d1 = MFCC_MFMA(ax[4 + r], lm1[r], d1);
+                }
+            }
+            MFCC_STAMP(8);
+            if (have_prev) dct_store(s, t, lm0, lm1, d0, d1, ax, prev, lo, q, lane_off, out);
+        } else if (role == 1) {
+            // column 16 -> bins 16 + 32 j of this tile (a 16 x 16 real DFT matrix, two chains of two MFMAs),
+            // fed to both filter blocks from registers at the end; its chain hides among the mel MFMAs
+            const float v0 = Vt[lo * kVStride + 0 + q], v1 = Vt[lo * kVStride + 4 + q];
+            const float v2 = Vt[lo * kVStride + 8 + q], v3 = Vt[lo * kVStride + 12 + q];
+            f32x4 sp = MFCC_MFMA(ax[0], v0, zero);
+            f32x4 sp2 = MFCC_MFMA(ax[1], v1, zero);
+            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
+            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
+            sp = MFCC_MFMA(ax[2], v2, sp);
+            sp2 = MFCC_MFMA(ax[3], v3, sp2);
+            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
+            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
+#pragma unroll
+            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
+                if ((k2 - kB1_LO) & 1) y1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], y1);
+                else x1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], x1);
+            }
             sp += sp2;
             const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
             const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
@@ -504,19 +535,19 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             y0 = MFCC_MFMA(ax[5], s1, y0);
             x1 = MFCC_MFMA(ax[6], s0, x1);
             y1 = MFCC_MFMA(ax[7], s1, y1);
-        }
-        x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
-        y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
-        x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
-        y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
+            MFCC_STAMP(8);
+        } else {
+            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
+            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
+            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
+            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
 #pragma unroll
-        for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
-            if ((k2 - kB1_LO) & 1) y1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], y1);
-            else x1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], x1);
+            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
+                if ((k2 - kB1_LO) & 1) y1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], y1);
+                else x1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], x1);
+            }
+            MFCC_STAMP(8);
         }
-        MFCC_STAMP(8);
-        // the previous tile's tail
-        if (role == 0 && have_prev) dct_store(s, t, lm0, lm1, ax, prev, lo, q, lane_off, out);
         MFCC_STAMP(9);
         *reinterpret_cast<f32x4 *>(Qt + (2 * wave + 0) * 256 + lane * 4) = x0 + y0;
         *reinterpret_cast<f32x4 *>(Qt + (2 * wave + 1) * 256 + lane * 4) = x1 + y1;
@@ -533,7 +564,13 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     // the last tile of this workgroup
     if (role == 0 && have_prev) {
         mel_log2(Qt, lane, lm0, lm1);
-        dct_store(s, t, lm0, lm1, ax, prev, lo, q, lane_off, out);
+        f32x4 d0 = zero, d1 = zero;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d0 = MFCC_MFMA(ax[r], lm0[r], d0);
+            d1 = MFCC_MFMA(ax[4 + r], lm1[r], d1);
+        }
+        dct_store(s, t, lm0, lm1, d0, d1, ax, prev, lo, q, lane_off, out);
     }
 #ifdef MFCC_FUSED_STAMPS
     if (lane == 0) {
