@@ -286,16 +286,10 @@ __device__ __forceinline__ void mel_log2(const float *Qt, int lane, int q, f32x4
     if (q >= 2) lm[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-__device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tables &t, const f32x4 (&lm)[kBlocks],
-                                          const float (&ax)[kAextra], const Cursor &c, int lo, int q, int lane_off,
-                                          float *__restrict__ out) {
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        d0 = MFCC1K_MFMA(ax[r], lm[0][r], d0);
-        d1 = MFCC1K_MFMA(ax[4 + r], lm[1][r], d1);
-        d2 = MFCC1K_MFMA(ax[8 + r], lm[2][r], d2);
-    }
+// d[0] + d[1] + d[2] = the DCT of the previous tile (its 12 MFMAs are issued by the caller)
+__device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tables &t, const f32x4 (&d)[kBlocks],
+                                          const Cursor &c, int lo, int q, int lane_off, float *__restrict__ out) {
+    const f32x4 d0 = d[0], d1 = d[1], d2 = d[2];
     const long long fr0 = (long long)c.t_in * kTile;
     const long long rows_left = s.frames_per_ch - fr0;
     if (lo < rows_left) {
@@ -303,6 +297,17 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tab
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < t.n_cep) o[r] = (d0[r] + d1[r]) + d2[r];
+    }
+}
+
+// role 0 (wave 0, h = 0): this tile's 17 mel MFMAs and the previous tile's 12 DCT MFMAs in one basic block,
+// interleaved -- six independent accumulator chains instead of two long tails
+__device__ __forceinline__ void mel_dct_mfmas(const float (&pw)[16], const float (&am)[kAmel], const float (&ax)[kAextra],
+                                              const f32x4 (&lm)[kBlocks], f32x4 (&acc)[kBlocks], f32x4 (&d)[kBlocks]) {
+#pragma unroll
+    for (int i = 0; i < kN0; ++i) {
+        acc[kB0[i]] = MFCC1K_MFMA(am[i], pw[kM0[i]], acc[kB0[i]]);
+        if (i < 12) d[i % 3] = MFCC1K_MFMA(ax[4 * (i % 3) + i / 3], lm[i % 3][i / 3], d[i % 3]);
     }
 }
 
@@ -439,9 +444,15 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
                 for (int i = 0; i < kNS2; ++i) acc[kS2blk[i]] = MFCC1K_MFMA(ax[8 + i], kS2step[i] ? s1 : s0, acc[kS2blk[i]]);
             }
         }
-        if (h) mel_mfmas<1>(pw, am, acc);
-        else mel_mfmas<0>(pw, am, acc);
-        if (role == 0 && have_prev) dct_store(s, t, lm, ax, prev, lo, q, lane_off, out);
+        if (role == 0) {
+            f32x4 d[kBlocks] = {zero, zero, zero};
+            mel_dct_mfmas(pw, am, ax, lm, acc, d);           // lm = 0 before the first tile
+            if (have_prev) dct_store(s, t, d, prev, lo, q, lane_off, out);
+        } else if (h) {
+            mel_mfmas<1>(pw, am, acc);
+        } else {
+            mel_mfmas<0>(pw, am, acc);
+        }
 #pragma unroll
         for (int b = 0; b < kBlocks; ++b)
             *reinterpret_cast<f32x4 *>(Qt + ((wave * kBlocks + b) * 64 + lane) * 4) = acc[b];
@@ -453,7 +464,12 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
     }
     if (role == 0 && have_prev) {
         mel_log2(Qt, lane, q, lm);
-        dct_store(s, t, lm, ax, prev, lo, q, lane_off, out);
+        f32x4 d[kBlocks] = {zero, zero, zero};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) d[b] = MFCC1K_MFMA(ax[4 * b + r], lm[b][r], d[b]);
+        dct_store(s, t, d, prev, lo, q, lane_off, out);
     }
 }
 
