@@ -252,6 +252,19 @@ def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
     assert e_max <= TOL and e_l2 <= TOL
 
 
+@pytest.mark.parametrize("sr", [8000, 22050, 44100])
+def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
+    """The fused kernels hard-wire the band structure of the mel matrix at 16 kHz; their table builders
+    check every non-zero weight is covered and otherwise leave the parameter set to the generic kernel."""
+    x = mf.synth_pcm(30000, seed=2)
+    for nfft, nmel in ((512, 32), (1024, 40)):
+        with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
+            got = m.process(x)
+        ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
+        e_max, e_l2 = _err(got, ref)
+        assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
+
+
 def test_float_linearity_property_full_size(mfcc_amd):
     """Size-independent property at config-2 size (10 min): scaling the input by 2 adds
     exactly 2*sqrt(32) to c0 (log2 of 4x power through the ortho DCT) and leaves c1.. unchanged."""
