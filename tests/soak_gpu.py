@@ -4,7 +4,7 @@ Random channel counts, lengths, channel strides and base offsets (all alignment 
 framing mode, n_cep 1..32 and six signal kinds (Gaussian at three levels, full-scale uniform, Gaussian
 with a stretch of silence, DC, full-scale square, pure sine).  Fixed contract: the fused fixed-point
 kernel against oracle/mfcc_fixed.py, bit for bit.  Float contract: the fused 512 and 1024 kernels against
-the generic kernel (3e-5 of the largest coefficient; DC / square / sine inputs have mel bands at the fp32
+the generic kernel (5e-5 of the largest coefficient; DC / square / sine inputs have mel bands at the fp32
 noise floor where two fp32 FFTs legitimately differ after the log -- DESIGN.md section 1 -- so they are
 reported, not counted, unless FUZZ_STRICT is set).  FUZZ_FIXED=1 restricts the run to the fixed contract."""
 import os, sys, time, numpy as np
@@ -40,6 +40,20 @@ def close(a, b, tol):
 t0 = time.time(); cases = fails = 0
 while time.time() - t0 < budget:
     cases += 1
+    if rng.random() < 0.08:                      # ragged batch vs per-utterance calls, bit for bit
+        nfft_r = int(rng.choice([512, 1024])); pad = str(rng.choice(["notebook", "stream"]))
+        utts = [signal(int(rng.integers(0, 6000)), int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 12)))]
+        try:
+            with mfcc_amd.MFCC(nfft=nfft_r, nfilters=32 if nfft_r == 512 else 40, nceptrums=int(rng.integers(1, 17)),
+                               pad_mode=pad, power_scale=0) as m:
+                fl = m.process_batch(utts)
+                fx = m.process_batch(utts, fixed=True) if nfft_r == 512 else None
+                for i, u in enumerate(utts):
+                    if not np.array_equal(fl[i], m.process(u), equal_nan=True): fails += 1; print("RAGGED FLOAT MISMATCH", nfft_r, pad, i, len(u))
+                    if fx is not None and not np.array_equal(fx[i], m.process_fixed(u)): fails += 1; print("RAGGED FIXED MISMATCH", pad, i, len(u))
+        except Exception as e:
+            fails += 1; print("EXC ragged", repr(e)[:200])
+        continue
     big = rng.random() < 0.5
     cfg = "x512" if os.environ.get("FUZZ_FIXED") else rng.choice(["f512", "f1024", "x512"])
     nfft, hop = (1024, 341) if cfg == "f1024" else (512, 170)
@@ -73,7 +87,7 @@ while time.time() - t0 < budget:
                       power_scale=512.0 if cfg == "f512" else 0)
             with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
                 ga = a.process(view, halo=halo).cpu().numpy(); gb = b.process(view, halo=halo).cpu().numpy()
-            ok, why = close(ga, gb, 3e-5)
+            ok, why = close(ga, gb, 5e-5)
             if not ok and (os.environ.get("FUZZ_STRICT") or not noisy):
                 fails += 1; print("FLOAT MISMATCH", tag, why)
     except Exception as e:
