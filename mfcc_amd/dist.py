@@ -121,3 +121,13 @@ def process_items_sharded(compute: Callable, items: Sequence, rank: int, world: 
     """This rank's utterances: returns (indices, [compute(item) for item in mine])."""
     mine = plan_items(len(items), world)[rank]
     return list(mine), [compute(items[i]) for i in mine]
+
+
+def process_corpus_sharded(batch_compute: Callable, items: Sequence, rank: int, world: int):
+    """Config 5 (a corpus of short utterances): this rank's utterances in ONE ragged launch.
+    ``batch_compute`` maps a list of utterances to the list of their coefficient arrays --
+    ``MFCC.process_batch`` (or ``lambda u: m.process_batch(u, fixed=True)``).  Returns (indices, results)."""
+    mine = plan_items(len(items), world)[rank]
+    outs = batch_compute([items[i] for i in mine]) if len(mine) else []
+    assert len(outs) == len(mine)
+    return list(mine), list(outs)

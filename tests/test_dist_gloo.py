@@ -64,6 +64,17 @@ def _worker(rank, world, port, kind, q):
         elif kind == "fixed_stream":
             nf = mf.num_frames_stream(len(pcm))
             shard, loc = md.process_frames_sharded(_fixed_compute, pcm, rank, world, 13, n_frames=nf)
+        elif kind == "corpus":                       # one batch call per rank (MFCC.process_batch in production)
+            items = [mf.synth_pcm(3000 + 500 * i, seed=i) for i in range(5)]
+            calls = []
+
+            def batch(us):
+                calls.append(len(us))
+                return [mf.mfcc_float_ref(u) for u in us]
+            idx, outs = md.process_corpus_sharded(batch, items, rank, world)
+            assert calls == [len(idx)]               # exactly one launch for the whole shard
+            loc = np.concatenate(outs) if outs else np.zeros((0, 13))
+            shard = None
         else:                                        # items
             items = [mf.synth_pcm(3000 + 500 * i, seed=i) for i in range(5)]
             idx, outs = md.process_items_sharded(lambda u: mf.mfcc_float_ref(u), items, rank, world)
@@ -116,6 +127,14 @@ def test_frame_sharding_fixed_stream_padding_is_bit_exact():
 
 def test_item_sharding():
     res = _run("items")
+    items = [mf.synth_pcm(3000 + 500 * i, seed=i) for i in range(5)]
+    ref = np.concatenate([mf.mfcc_float_ref(u) for u in items])
+    for rank, full, _ in res:
+        np.testing.assert_array_equal(full, ref)
+
+
+def test_corpus_sharding_one_batch_per_rank():
+    res = _run("corpus")
     items = [mf.synth_pcm(3000 + 500 * i, seed=i) for i in range(5)]
     ref = np.concatenate([mf.mfcc_float_ref(u) for u in items])
     for rank, full, _ in res:
