@@ -59,7 +59,8 @@ constexpr int kTFrame = 16 * kTRow + 2;   // 546 words per frame (== 2 mod 32): 
                                           // per access) -- 16 distinct 8-byte bank pairs; 548 cost a 2-way
                                           // conflict on every one of them (SQ_LDS_BANK_CONFLICT)
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
-constexpr int kAmel = 17;                 // mel A operands per wave: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
+constexpr int kAmelBanded = 17;           // mel A operands per wave at 16 kHz: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
+constexpr int kAmelDense = 32;            // any other band structure: every (k2, block) pair
 constexpr int kAextra = 16;               // role operands: role 0 DCT (8 + 8 for coefficients 16..31); role 1
                                           // column-16 DFT (4) + its mel (4)
 constexpr int kFetchers = 192;            // threads that fetch and park the sample window: roles 1..3
@@ -85,16 +86,33 @@ struct FusedTables {
 // Filters 0..15 ("block 0") only touch bins < 64 -> k2 in {0, 1, 14, 15}; filters 16..31 only bins
 // >= 48 -> k2 in 2..14 (both checked by build_tables): 17 MFMAs per wave, the same code in every wave.
 // Bins == 16 (mod 32) come from column 16 and are fed by role 1.
-constexpr int kB0_K2[4] = {0, 1, 14, 15};
-constexpr int kB1_LO = 2, kB1_HI = 15;
+// The list of (k2, block) MFMAs of a wave.  BANDED is the 16 kHz structure above; DENSE issues all 32 pairs and
+// so serves any sample rate (other mel band edges) at the price of 15 more MFMAs per wave.
+template <bool DENSE>
+struct Sched;
+template <>
+struct Sched<false> {
+    static constexpr int N = kAmelBanded;
+    static constexpr int k2[N] = {0, 1, 14, 15, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14};
+    static constexpr int blk[N] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+};
+template <>
+struct Sched<true> {
+    static constexpr int N = kAmelDense;
+    static constexpr int k2[N] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    static constexpr int blk[N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+};
 
 inline bool supported(int nfft, int hop, int n_mel, int n_cep) {
     return nfft == kNfft && hop == kHop && n_mel == kMel && n_cep >= 1 && n_cep <= kMaxCep;
 }
 
 // ---- host: constant tables in the exact order the kernel consumes them
+template <bool DENSE>
 inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep,
                          std::vector<char> &blob) {
+    constexpr int kAmel = Sched<DENSE>::N;
     using namespace mfcc_tables;
     std::vector<float> win(16 * 32), tw(16 * 16 * 2), amel(size_t(kWaves) * kAmel * 64, 0.0f),
         aext(size_t(kWaves) * kAextra * 64, 0.0f);
@@ -123,10 +141,7 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         }
     };
     for (int wv = 0; wv < kWaves; ++wv) {
-        int idx = 0;
-        for (int i = 0; i < 4; ++i) mel_op(wv, idx++, 0, kB0_K2[i]);
-        for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) mel_op(wv, idx++, 1, k2);
-        if (idx != kAmel) return false;
+        for (int idx = 0; idx < kAmel; ++idx) mel_op(wv, idx, Sched<DENSE>::blk[idx], Sched<DENSE>::k2[idx]);
     }
     // role 0 -- DCT rows: lane (coeff = l&15, g = l>>4) holds D[16 half + coeff][16 blk + 4 g + r]
     std::vector<double> dd = dct_rows(n_cep, kMel, lifter);                    // [n_cep][32]
@@ -167,7 +182,8 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     return true;
 }
 
-inline void bind_tables(const char *b, int n_cep, FusedTables &t) {
+inline void bind_tables(const char *b, int n_cep, bool dense, FusedTables &t) {
+    const int kAmel = dense ? kAmelDense : kAmelBanded;
     // device pointer arithmetic only; layout = build_tables' put() order
     t.n_cep = n_cep;
     const float *f = reinterpret_cast<const float *>(b);
@@ -365,8 +381,44 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Fus
     }
 }
 
+// one mel MFMA of the schedule: block 0 accumulates in (x0, y0), block 1 in (x1, y1), alternating
+template <bool DENSE, int I>
+__device__ __forceinline__ void mel_step(const float (&am)[Sched<DENSE>::N], const float (&pw)[16], f32x4 &x0, f32x4 &y0,
+                                         f32x4 &x1, f32x4 &y1) {
+    constexpr int k2 = Sched<DENSE>::k2[I], blk = Sched<DENSE>::blk[I];
+    f32x4 &acc = blk ? ((I & 1) ? y1 : x1) : ((I & 1) ? y0 : x0);
+    acc = MFCC_MFMA(am[I], pw[k2], acc);
+}
+
+template <bool DENSE, int LO, int HI>
+__device__ __forceinline__ void mel_steps(const float (&am)[Sched<DENSE>::N], const float (&pw)[16], f32x4 &x0, f32x4 &y0,
+                                          f32x4 &x1, f32x4 &y1) {
+    if constexpr (LO < HI) {
+        mel_step<DENSE, LO>(am, pw, x0, y0, x1, y1);
+        mel_steps<DENSE, LO + 1, HI>(am, pw, x0, y0, x1, y1);
+    }
+}
+
+// role 0: mel MFMAs with one DCT MFMA (coefficients 0..15 of the previous tile) after every second one
+template <bool DENSE, int I>
+__device__ __forceinline__ void mel_dct_steps(const float (&am)[Sched<DENSE>::N], const float (&pw)[16],
+                                              const float (&ax)[kAextra], const f32x4 &lm0, const f32x4 &lm1, f32x4 &x0,
+                                              f32x4 &y0, f32x4 &x1, f32x4 &y1, f32x4 &d0, f32x4 &d1) {
+    if constexpr (I < Sched<DENSE>::N) {
+        mel_step<DENSE, I>(am, pw, x0, y0, x1, y1);
+        if constexpr ((I & 1) && I / 2 < 8) {
+            constexpr int j = I / 2, r = j >> 1;
+            if constexpr (j & 1) d1 = MFCC_MFMA(ax[4 + r], lm1[r], d1);
+            else d0 = MFCC_MFMA(ax[r], lm0[r], d0);
+        }
+        mel_dct_steps<DENSE, I + 1>(am, pw, ax, lm0, lm1, x0, y0, x1, y1, d0, d1);
+    }
+}
+
+template <bool DENSE>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
+    constexpr int kAmel = Sched<DENSE>::N;
     __shared__ __attribute__((aligned(16))) float lds[kLdsWords];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -491,23 +543,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             // interleaved: six independent accumulator chains instead of two long tails (lm = 0 before the
             // first tile; only the store depends on have_prev)
             f32x4 d0 = zero, d1 = zero;
-            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
-            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
-            d0 = MFCC_MFMA(ax[0], lm0[0], d0);
-            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
-            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
-            d1 = MFCC_MFMA(ax[4], lm1[0], d1);
-#pragma unroll
-            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
-                const int i = k2 - kB1_LO;
-                if (i & 1) y1 = MFCC_MFMA(am[4 + i], pw[k2], y1);
-                else x1 = MFCC_MFMA(am[4 + i], pw[k2], x1);
-                if (i >= 1 && i <= 6) {                       // six more DCT MFMAs, one every mel MFMA
-                    const int r = (i + 1) >> 1;               // 1,1,2,2,3,3
-                    if (i & 1) d0 = MFCC_MFMA(ax[r], lm0[r], d0);
-                    else d1 = MFCC_MFMA(ax[4 + r], lm1[r], d1);
-                }
-            }
+            mel_dct_steps<DENSE, 0>(am, pw, ax, lm0, lm1, x0, y0, x1, y1, d0, d1);
             MFCC_STAMP(8);
             if (have_prev) dct_store(s, t, lm0, lm1, d0, d1, ax, prev, lo, q, lane_off, out);
         } else if (role == 1) {
@@ -517,17 +553,10 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             const float v2 = Vt[lo * kVStride + 8 + q], v3 = Vt[lo * kVStride + 12 + q];
             f32x4 sp = MFCC_MFMA(ax[0], v0, zero);
             f32x4 sp2 = MFCC_MFMA(ax[1], v1, zero);
-            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
-            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
+            mel_steps<DENSE, 0, 2>(am, pw, x0, y0, x1, y1);
             sp = MFCC_MFMA(ax[2], v2, sp);
             sp2 = MFCC_MFMA(ax[3], v3, sp2);
-            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
-            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
-#pragma unroll
-            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
-                if ((k2 - kB1_LO) & 1) y1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], y1);
-                else x1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], x1);
-            }
+            mel_steps<DENSE, 2, kAmel>(am, pw, x0, y0, x1, y1);
             sp += sp2;
             const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
             const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
@@ -537,15 +566,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             y1 = MFCC_MFMA(ax[7], s1, y1);
             MFCC_STAMP(8);
         } else {
-            x0 = MFCC_MFMA(am[0], pw[kB0_K2[0]], x0);
-            y0 = MFCC_MFMA(am[1], pw[kB0_K2[1]], y0);
-            x0 = MFCC_MFMA(am[2], pw[kB0_K2[2]], x0);
-            y0 = MFCC_MFMA(am[3], pw[kB0_K2[3]], y0);
-#pragma unroll
-            for (int k2 = kB1_LO; k2 < kB1_HI; ++k2) {
-                if ((k2 - kB1_LO) & 1) y1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], y1);
-                else x1 = MFCC_MFMA(am[4 + k2 - kB1_LO], pw[k2], x1);
-            }
+            mel_steps<DENSE, 0, kAmel>(am, pw, x0, y0, x1, y1);
             MFCC_STAMP(8);
         }
         MFCC_STAMP(9);
@@ -583,7 +604,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
 inline const char *kernel_name() { return "mfcc_fused512_kernel"; }
 
 // returns false when the problem does not fit the kernel's 32-bit tile arithmetic
-inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, float *out, int n_cu,
+inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense, float *out, int n_cu,
                    hipStream_t stream) {
     const long long tiles_per_ch = (s.frames_per_ch + kTile - 1) / kTile;
     const long long n_ch = s.total_frames / s.frames_per_ch;
@@ -603,7 +624,10 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, float *out
     if (g.t_lo < 0) g.t_lo = 0;
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
-    hipLaunchKernelGGL(mfcc_fused512_kernel, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    if (dense)
+        hipLaunchKernelGGL(mfcc_fused512_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    else
+        hipLaunchKernelGGL(mfcc_fused512_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
     return true;
 }
 

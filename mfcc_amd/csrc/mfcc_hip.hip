@@ -109,6 +109,7 @@ struct mfcc_hip_handle {
     int n_cu = 0;
     bool fixed_ok = false;
     bool fused_ok = false;
+    bool fused_dense = false;     // the fused kernel's banded MFMA list does not fit this sample rate: all pairs
     bool fused1k_ok = false;      // the fused 1024/341/40 float kernel covers this handle's parameters
     bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
@@ -209,8 +210,15 @@ int build_tables(mfcc_hip_handle *h) {
 
     // ---- fused 512/170/32 kernel tables
     std::vector<char> fused_blob;
-    h->fused_ok = mfcc_fused::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
-                  mfcc_fused::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+    h->fused_ok = false;
+    h->fused_dense = false;
+    if (mfcc_fused::supported(r.nfft, r.hop, r.n_mel, r.n_cep)) {
+        h->fused_ok = mfcc_fused::build_tables<false>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+        if (!h->fused_ok) {
+            h->fused_dense = true;
+            h->fused_ok = mfcc_fused::build_tables<true>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+        }
+    }
     size_t o_fu = 0;
     if (h->fused_ok) o_fu = a.put(fused_blob);
     std::vector<char> f1k_blob;
@@ -247,7 +255,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.log2_dct = ilog2(4 * r.n_mel);
         h->xt.n_cep = r.n_cep;
     }
-    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fu);
+    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fused_dense, h->fu);
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
@@ -301,7 +309,7 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds,
                            h->stream, s, h->xt, static_cast<int16_t *>(d_out));
     } else if (use_fused(h)) {
-        if (!mfcc_fused::launch(s, h->fu, static_cast<float *>(d_out), h->n_cu, h->stream))
+        if (!mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
     } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
                mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) {

@@ -254,12 +254,15 @@ def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
 
 @pytest.mark.parametrize("sr", [8000, 22050, 44100])
 def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
-    """The fused kernels hard-wire the band structure of the mel matrix at 16 kHz; their table builders
-    check every non-zero weight is covered and otherwise leave the parameter set to the generic kernel."""
+    """The banded MFMA lists of the fused kernels are the band structure of the mel matrix at 16 kHz; their
+    table builders check every non-zero weight is covered.  Otherwise the 512 kernel switches to its dense
+    instantiation (all 32 (k2, block) pairs, any rate) and the 1024 kernel leaves the set to the generic one."""
     x = mf.synth_pcm(30000, seed=2)
     for nfft, nmel in ((512, 32), (1024, 40)):
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
             got = m.process(x)
+            if nfft == 512:
+                assert m.kernel_name().endswith("fused512_kernel")
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
