@@ -131,41 +131,13 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (x0 +- a) >> 1 with 16-bit wrap on packed x0; a1 / a2 are the rotated x1 (re, im).  8 VALU ops: four
-// SDWA adds that sign-extend x0's halves on the fly, and per output a shift plus an SDWA shift that
-// lands in the high word (the 16-bit wrap is the truncation to a half).
+// the packed butterfly (12 VALU ops) lives in kernels_generic.hpp: fx_combine / fx_rot14 / fx_bfly
 __device__ __forceinline__ void combine(uint32_t p0, int a1, int a2, uint32_t &o0, uint32_t &o1) {
-    int t0, t1, t2, t3;
-    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
-        : "=v"(t0) : "v"(p0), "v"(a1));
-    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
-        : "=v"(t1) : "v"(p0), "v"(a1));
-    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-        : "=v"(t2) : "v"(p0), "v"(a2));
-    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-        : "=v"(t3) : "v"(p0), "v"(a2));
-    const int one = 1;
-    uint32_t r0 = (uint32_t)t0 >> 1, r1 = (uint32_t)t1 >> 1;
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-        : "+v"(r0) : "s"(one), "v"(t2));
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-        : "+v"(r1) : "s"(one), "v"(t3));
-    o0 = r0;
-    o1 = r1;
+    mfcc_k::fx_combine(p0, a1, a2, o0, o1);
 }
-
-// x1r*twr - x1i*twi + 8191 (operand A) / x1r*twi + x1i*twr + 8191 (operand B): the three-operand form of
-// the dot product (the builtin becomes v_dot2c, which needs a v_mov of the bias first)
-__device__ __forceinline__ int rot14(uint32_t p1, uint32_t tw) {
-    const int bias = 8191;
-    int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(p1), "v"(tw), "s"(bias));
-    return r >> 14;
-}
-
-// general butterfly, misc/fft.py:140-192
+__device__ __forceinline__ int rot14(uint32_t p1, uint32_t tw) { return mfcc_k::fx_rot14(p1, tw); }
 __device__ __forceinline__ void bfly(uint32_t &p0, uint32_t &p1, uint32_t twa, uint32_t twb) {
-    combine(p0, rot14(p1, twa), rot14(p1, twb), p0, p1);
+    mfcc_k::fx_bfly(p0, p1, twa, twb);
 }
 
 // twiddle T[0] = (16384, 0): (x * 16384 + 8191) >> 14 == x

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
 
 struct FixedTables {
     const int   *curve;       // [nfft]     window curve (mfcc/core/window.py)
-    const int2  *tw_fft;      // [nfft/2]   Q14 twiddles of the nfft-point FFT
-    const int2  *tw_dct;      // [2*n_mel]  Q14 twiddles of the (4*n_mel)-point FFT
+    const uint2 *tw_fft;      // [nfft/2]   Q14 twiddles of the nfft-point FFT as dot2 operand pairs (see fx_bfly)
+    const uint2 *tw_dct;      // [2*n_mel]  the same for the (4*n_mel)-point FFT
     const int   *mel_start;   // [n_mel]
     const int   *mel_count;   // [n_mel]
     const int   *mel_off;     // [n_mel]
@@ -194,18 +194,50 @@ struct FixedTables {
 
 __device__ __forceinline__ int wrap16(int v) { return (int)(short)(v & 0xFFFF); }
 
-// mfcc/misc/fft.py:140-192 butterfly, bias 8191, >>14, then the per-stage >>1
-__device__ __forceinline__ void fx_butterfly(int2 x0, int2 x1, int2 tw, int2 &y0, int2 &y1) {
-    int m0 = (x1.x + x1.y) * tw.x + 8191;
-    int a1 = (m0 - x1.y * (tw.x + tw.y)) >> 14;
-    int a2 = (m0 - x1.x * (tw.x - tw.y)) >> 14;
-    y0 = make_int2(wrap16((x0.x + a1) >> 1), wrap16((x0.y + a2) >> 1));
-    y1 = make_int2(wrap16((x0.x - a1) >> 1), wrap16((x0.y - a2) >> 1));
+// ---- packed fixed-point butterfly, shared with kernel_fixed512.hpp.  A complex value is one dword, (re, im)
+// as two int16 (every stage wraps to 16 bits anyway); a twiddle is a pair of dot2 operands:
+// A = (twr, -twi) gives s1 = x1r*twr - x1i*twi, B = (twi, twr) gives s2 = x1r*twi + x1i*twr -- the same integers as
+// the RTL's three-multiplier form (mfcc/misc/fft.py:140-192; nothing overflows 33 bits).
+
+// (x0 +- a) >> 1 with 16-bit wrap on packed x0; a1 / a2 are the rotated x1 (re, im).  8 VALU ops: four
+// SDWA adds that sign-extend x0's halves on the fly, and per output a shift plus an SDWA shift that
+// lands in the high word (the 16-bit wrap is the truncation to a half).
+__device__ __forceinline__ void fx_combine(uint32_t p0, int a1, int a2, uint32_t &o0, uint32_t &o1) {
+    int t0, t1, t2, t3;
+    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t0) : "v"(p0), "v"(a1));
+    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+        : "=v"(t1) : "v"(p0), "v"(a1));
+    asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(t2) : "v"(p0), "v"(a2));
+    asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(t3) : "v"(p0), "v"(a2));
+    const int one = 1;
+    uint32_t r0 = (uint32_t)t0 >> 1, r1 = (uint32_t)t1 >> 1;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r0) : "s"(one), "v"(t2));
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r1) : "s"(one), "v"(t3));
+    o0 = r0;
+    o1 = r1;
 }
 
-// in-place radix-2 DIT over `size` points held in LDS (bit-reversed input order);
-// schedule of mfcc/misc/fft.py:216-344 (see oracle/mfcc_fixed.py: fft_fixed)
-__device__ __forceinline__ void fx_fft_inplace(int2 *x, int size, int L, const int2 *tw, int lane) {
+// (dot2(p1, tw) + 8191) >> 14: the three-operand form of the dot product (the builtin becomes v_dot2c, which
+// needs a v_mov of the bias first)
+__device__ __forceinline__ int fx_rot14(uint32_t p1, uint32_t tw) {
+    const int bias = 8191;
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(p1), "v"(tw), "s"(bias));
+    return r >> 14;
+}
+
+__device__ __forceinline__ void fx_bfly(uint32_t &p0, uint32_t &p1, uint32_t twa, uint32_t twb) {
+    fx_combine(p0, fx_rot14(p1, twa), fx_rot14(p1, twb), p0, p1);
+}
+
+// in-place radix-2 DIT over `size` packed points held in LDS (bit-reversed input order); schedule of
+// mfcc/misc/fft.py:216-344 (see oracle/mfcc_fixed.py: fft_fixed); tw: packed operand pairs [size/2]
+__device__ __forceinline__ void fx_fft_inplace(uint32_t *x, int size, int L, const uint2 *tw, int lane) {
     const int half = size >> 1;
     for (int st = 0; st < L; ++st) {
         for (int tp = lane; tp < half; tp += 64) {
@@ -213,12 +245,13 @@ __device__ __forceinline__ void fx_fft_inplace(int2 *x, int size, int L, const i
             const int i0 = ((tp >> st) << (st + 1)) | j;
             const int i1 = i0 + (1 << st);
             const int ta = (j << (L - 1 - st)) & (half - 1);
-            int2 y0, y1;
-            fx_butterfly(x[i0], x[i1], tw[ta], y0, y1);
-            x[i0] = y0;
-            x[i1] = y1;
+            uint32_t p0 = x[i0], p1 = x[i1];
+            const uint2 w = tw[ta];
+            fx_bfly(p0, p1, w.x, w.y);
+            x[i0] = p0;
+            x[i1] = p1;
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -227,14 +260,14 @@ constexpr int kFxMaxNfft = 1024;
 __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedTables t,
                                                           int16_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // per wave: int2 x[nfft]; uint32 P[nfft/2] aliases nothing (separate); int mel[64]
+    // per wave (nothing is shared between waves): uint32 x[nfft] packed (re, im); uint32 P[nfft/2]; int mel[64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nfft = t.nfft;
-    int2 *x = reinterpret_cast<int2 *>(smem) + (size_t)wave * nfft;
-    uint32_t *P = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(int2)) +
+    uint32_t *x = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * nfft;
+    uint32_t *P = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(uint32_t)) +
                   (size_t)wave * (nfft / 2);
-    int *melv = reinterpret_cast<int *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(int2) +
+    int *melv = reinterpret_cast<int *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(uint32_t) +
                                         (size_t)kWavesPerBlock * (nfft / 2) * sizeof(uint32_t)) +
                 wave * kMaxMel;
 
@@ -258,18 +291,18 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
             int y = wrap16(x0 + (o >> 5) - o);
             int w = (y * t.curve[i]) >> 9;
             int r = (int)(__brev((unsigned)i) >> (32 - L));
-            x[r] = make_int2(w, 0);
+            x[r] = (uint32_t)w & 0xffffu;
         }
-        __syncthreads();
+        wave_sync();
         fx_fft_inplace(x, nfft, L, t.tw_fft, lane);
 
         // pow2.py:32,64  (re^2 + im^2) >> 2, 30 bits
         for (int k = lane; k < nfft / 2; k += 64) {
-            int2 v = x[k];
-            uint32_t r = (uint32_t)(v.x * v.x) + (uint32_t)(v.y * v.y);
+            const int re = (int)(short)(x[k] & 0xffffu), im = (int)x[k] >> 16;
+            uint32_t r = (uint32_t)(re * re) + (uint32_t)(im * im);
             P[k] = r >> 2;
         }
-        __syncthreads();
+        wave_sync();
 
         // filterbank.py:88-142 in closed form (tables.hpp: fx_mel), then log.py Log2Fix(16, 15)
         if (lane < t.n_mel) {
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
             }
             melv[lane] = (int)(o & 0x7FFFu);
         }
-        __syncthreads();
+        wave_sync();
 
         // dct_stream.py:23-33: y[2n+1] = y[size-1-2n] = x[n], zeros elsewhere; FFT(4*n_mel)
         const int dsz = 4 * t.n_mel;
@@ -301,12 +334,12 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
                 v = melv[n];
             }
             int r = (int)(__brev((unsigned)i) >> (32 - t.log2_dct));
-            x[r] = make_int2(v, 0);
+            x[r] = (uint32_t)v & 0xffffu;
         }
-        __syncthreads();
+        wave_sync();
         fx_fft_inplace(x, dsz, t.log2_dct, t.tw_dct, lane);
-        if (valid && lane < t.n_cep) out[fid * t.n_cep + lane] = (int16_t)x[lane].x;
-        __syncthreads();
+        if (valid && lane < t.n_cep) out[fid * t.n_cep + lane] = (int16_t)(x[lane] & 0xffffu);
+        wave_sync();
     }
 }
 

@@ -187,11 +187,15 @@ int build_tables(mfcc_hip_handle *h) {
         std::vector<int> cv = fx_window_curve(r.nfft);
         std::vector<int> re, im;
         fx_twiddles(r.nfft, re, im);
-        std::vector<int2> t1(re.size());
-        for (size_t i = 0; i < re.size(); ++i) t1[i] = make_int2(re[i], im[i]);
+        // twiddles as dot2 operand pairs: A = (twr, -twi), B = (twi, twr) (kernels_generic.hpp: fx_bfly)
+        auto pack = [](int tre, int tim) {
+            return make_uint2((uint32_t(tre) & 0xffffu) | (uint32_t(-tim) << 16), (uint32_t(tim) & 0xffffu) | (uint32_t(tre) << 16));
+        };
+        std::vector<uint2> t1(re.size());
+        for (size_t i = 0; i < re.size(); ++i) t1[i] = pack(re[i], im[i]);
         fx_twiddles(4 * r.n_mel, re, im);
-        std::vector<int2> t2(re.size());
-        for (size_t i = 0; i < re.size(); ++i) t2[i] = make_int2(re[i], im[i]);
+        std::vector<uint2> t2(re.size());
+        for (size_t i = 0; i < re.size(); ++i) t2[i] = pack(re[i], im[i]);
         fm = fx_mel(r.nfft, r.n_mel, double(r.sample_rate));
         std::vector<uint32_t> xw;
         SparseRows xs = pack_rows(fm.dense, r.n_mel, r.nfft / 2, xw);
@@ -242,8 +246,8 @@ int build_tables(mfcc_hip_handle *h) {
     h->ft.n_cep = r.n_cep;
     if (h->fixed_ok) {
         h->xt.curve = reinterpret_cast<const int *>(b + o_cv);
-        h->xt.tw_fft = reinterpret_cast<const int2 *>(b + o_xt);
-        h->xt.tw_dct = reinterpret_cast<const int2 *>(b + o_xd);
+        h->xt.tw_fft = reinterpret_cast<const uint2 *>(b + o_xt);
+        h->xt.tw_dct = reinterpret_cast<const uint2 *>(b + o_xd);
         h->xt.mel_start = reinterpret_cast<const int *>(b + o_xs);
         h->xt.mel_count = reinterpret_cast<const int *>(b + o_xc);
         h->xt.mel_off = reinterpret_cast<const int *>(b + o_xo);
@@ -305,7 +309,7 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         long long cap = (long long)h->n_cu * 8;
         if (blocks > cap) blocks = cap;
         size_t lds = size_t(mfcc_k::kWavesPerBlock) *
-                     (size_t(h->r.nfft) * sizeof(int2) + size_t(h->r.nfft / 2) * 4 + mfcc_k::kMaxMel * 4);
+                     (size_t(h->r.nfft) * sizeof(uint32_t) + size_t(h->r.nfft / 2) * 4 + mfcc_k::kMaxMel * 4);
         hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds,
                            h->stream, s, h->xt, static_cast<int16_t *>(d_out));
     } else if (use_fused(h)) {
