@@ -285,11 +285,19 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
 
         // preemph.py:24  y = wrap16(x + (o >> 5) - o);  window.py:84  (y * curve) >> 9;
         // fft.py:413-424 bit-reversed load, imag = 0
+        // frames that lie inside the stream (all but the first and the padded tail) take plain loads
+        const bool inside = valid && n0 - 1 >= -(long long)s.halo && n0 + nfft <= s.n_samples;
         for (int i = lane; i < nfft; i += 64) {
-            int x0 = valid ? sample_at_i(s, base, n0 + i) : 0;
-            int o = valid ? sample_at_i(s, base, n0 + i - 1) : 0;
+            int x0, o;
+            if (inside) {
+                x0 = base[n0 + i];
+                o = base[n0 + i - 1];
+            } else {
+                x0 = valid ? sample_at_i(s, base, n0 + i) : 0;
+                o = valid ? sample_at_i(s, base, n0 + i - 1) : 0;
+            }
             int y = wrap16(x0 + (o >> 5) - o);
-            int w = (y * t.curve[i]) >> 9;
+            int w = __mul24(y, t.curve[i]) >> 9;
             int r = (int)(__brev((unsigned)i) >> (32 - L));
             x[r] = (uint32_t)w & 0xffffu;
         }
