@@ -161,6 +161,16 @@ int  mfcc_hip_process_ragged_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, c
                                        size_t n_utterances, int16_t *out, size_t out_capacity,
                                        size_t *frame_offsets);
 
+/* The same with the utterances and the result in HBM (d_pcm: all utterances back to back, d_out: dense
+ * [sum frames][n_cep]); offsets / frame_offsets stay host arrays.  Asynchronous on the handle's stream
+ * like the other *_dev entry points; frame_offsets is complete on return. */
+int  mfcc_hip_process_ragged_i16_dev(mfcc_hip_handle *h, const void *d_pcm, const size_t *offsets,
+                                     size_t n_utterances, void *d_out, size_t out_capacity,
+                                     size_t *frame_offsets);
+int  mfcc_hip_process_ragged_fixed_i16_dev(mfcc_hip_handle *h, const void *d_pcm, const size_t *offsets,
+                                           size_t n_utterances, void *d_out, size_t out_capacity,
+                                           size_t *frame_offsets);
+
 /*
  * Device-resident buffers (HBM in, HBM out), asynchronous on the handle's stream.
  * d_pcm:  channel c starts at d_pcm + c * ch_stride_samples (int16 units).

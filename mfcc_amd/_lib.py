@@ -74,6 +74,10 @@ SYMBOLS = {
                                                     C.c_size_t, C.c_void_p]),
     "mfcc_hip_convert_wavs": (C.c_int, [_H, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_int,
                                         C.c_void_p]),
+    "mfcc_hip_process_ragged_i16_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p]),
+    "mfcc_hip_process_ragged_fixed_i16_dev": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                        C.c_size_t, C.c_void_p]),
     "mfcc_hip_abi_version": (C.c_int, []),
     "mfcc_hip_default_params": (C.c_int, [C.POINTER(Params)]),
     "mfcc_hip_create": (C.c_int, [C.POINTER(Params), C.POINTER(_H)]),

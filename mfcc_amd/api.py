@@ -208,6 +208,8 @@ class MFCC:
         walk, main.c:206-247).  ``utterances``: sequence of 1-D int16 arrays.  Returns a list of
         ``(frames_u, nceptrums)`` arrays (views of one result buffer), bit-identical to calling
         ``process`` / ``process_fixed`` on each utterance."""
+        if len(utterances) and _is_torch(utterances[0]):
+            return self._batch_dev(utterances, fixed)
         utts = [np.ascontiguousarray(u, dtype=np.int16).reshape(-1) for u in utterances]
         n = len(utts)
         offsets = np.zeros(n + 1, dtype=np.uint64)
@@ -220,6 +222,26 @@ class MFCC:
         fn = self._lib.mfcc_hip_process_ragged_fixed_i16 if fixed else self._lib.mfcc_hip_process_ragged_i16
         _lib.check(fn(self._h, flat.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n,
                       out.ctypes.data_as(C.c_void_p), out.size, fo.ctypes.data_as(C.c_void_p)), "process_ragged")
+        assert int(fo[-1]) == nf
+        return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
+
+    def _batch_dev(self, utterances, fixed):
+        """``process_batch`` for torch CUDA int16 tensors: stays on the device, asynchronous on the current stream."""
+        import torch
+        utts = [u.reshape(-1) for u in utterances]
+        if any(u.dtype != torch.int16 or not u.is_cuda for u in utts):
+            raise TypeError("device path needs CUDA(HIP) int16 tensors")
+        n = len(utts)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([u.numel() for u in utts], dtype=np.uint64)
+        flat = torch.cat(utts) if int(offsets[-1]) else torch.zeros(0, dtype=torch.int16, device=utts[0].device)
+        nf = sum(self.num_frames(u.numel()) for u in utts)
+        out = torch.empty((nf, self.nceptrums), device=utts[0].device, dtype=torch.int16 if fixed else torch.float32)
+        fo = np.zeros(n + 1, dtype=np.uint64)
+        self.set_stream(torch.cuda.current_stream(utts[0].device).cuda_stream)
+        fn = self._lib.mfcc_hip_process_ragged_fixed_i16_dev if fixed else self._lib.mfcc_hip_process_ragged_i16_dev
+        _lib.check(fn(self._h, C.c_void_p(flat.data_ptr()), offsets.ctypes.data_as(C.c_void_p), n,
+                      C.c_void_p(out.data_ptr()), out.numel(), fo.ctypes.data_as(C.c_void_p)), "process_ragged_dev")
         assert int(fo[-1]) == nf
         return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
 

@@ -119,6 +119,7 @@ struct mfcc_hip_handle {
     mfcc_fused::FusedTables fu{};
     mfcc_fixed512::Tables x5{};
     mfcc_fused1024::Tables f1k{};
+    std::vector<long long> ragged_desc;   // descriptor table of the last asynchronous ragged call (its H2D copy source)
     // scratch for the host-buffer entry points
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -394,6 +395,70 @@ __global__ void gather_rows_kernel(const OutT *__restrict__ src, OutT *__restric
         const long long s0 = desc[3 * u] * row, d0 = desc[3 * u + 1] * row, n = desc[3 * u + 2] * row;
         for (long long i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = src[s0 + i];
     }
+}
+
+// device-resident input: copy every utterance to its place in the packed stream
+__global__ void pack_utterances_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
+                                       const long long *__restrict__ desc, long long n_utt) {
+    // desc: (source offset, destination offset, samples) per utterance
+    for (long long u = blockIdx.x; u < n_utt; u += gridDim.x) {
+        const int16_t *s0 = src + desc[3 * u];
+        int16_t *d0 = dst + desc[3 * u + 1];
+        const long long n = desc[3 * u + 2];
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) d0[i] = s0[i];
+    }
+}
+
+template <typename OutT>
+int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, const size_t *offsets, size_t n_utt,
+                       OutT *d_out, size_t cap, size_t *frame_offsets) {
+    if (!h || !offsets || !frame_offsets) return MFCC_HIP_ERROR_INVALID_PARAM;
+    if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
+    const size_t hop = size_t(h->r.hop), nfft = size_t(h->r.nfft), ncep = size_t(h->r.n_cep);
+    std::vector<long long> &desc = h->ragged_desc; // [0, 3n): pack descriptors, [3n, 6n): row-gather descriptors; kept
+    desc.assign(6 * n_utt, 0);                     // alive in the handle: the H2D copy below is asynchronous
+    size_t pos = 0, total = 0;
+    frame_offsets[0] = 0;
+    for (size_t u = 0; u < n_utt; ++u) {
+        if (offsets[u + 1] < offsets[u]) return MFCC_HIP_ERROR_INVALID_PARAM;
+        const size_t n = offsets[u + 1] - offsets[u];
+        if (n && !d_pcm) return MFCC_HIP_ERROR_INVALID_PARAM;
+        const size_t nf = count_frames(h->r, n);
+        desc[3 * u] = (long long)offsets[u];
+        desc[3 * u + 1] = (long long)pos;
+        desc[3 * u + 2] = nf ? (long long)n : 0;
+        desc[3 * n_utt + 3 * u] = (long long)(pos / hop);
+        desc[3 * n_utt + 3 * u + 1] = (long long)total;
+        desc[3 * n_utt + 3 * u + 2] = (long long)nf;
+        total += nf;
+        frame_offsets[u + 1] = total;
+        if (nf) {
+            const size_t extent = std::max(n, hop * (nf - 1) + nfft);
+            pos = (pos + extent + 1 + hop - 1) / hop * hop;
+        }
+    }
+    if (total == 0) return MFCC_HIP_SUCCESS;
+    if (!d_out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    const size_t F = pos / hop, len = pos + nfft + hop;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
+    if (rc) return rc;
+    rc = ensure(h, &h->d_out, &h->d_out_bytes, F * ncep * sizeof(OutT) + desc.size() * sizeof(long long) + 64);
+    if (rc) return rc;
+    OutT *d_all = static_cast<OutT *>(h->d_out);
+    const size_t desc_off = (F * ncep * sizeof(OutT) + 7) & ~size_t(7);
+    long long *d_desc = reinterpret_cast<long long *>(static_cast<char *>(h->d_out) + desc_off);
+    HIP_TRY(h, hipMemsetAsync(h->d_in, 0, len * sizeof(int16_t), h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    const unsigned blocks = (unsigned)std::min<size_t>(n_utt, size_t(h->n_cu) * 8);
+    hipLaunchKernelGGL(pack_utterances_kernel, dim3(blocks), dim3(256), 0, h->stream, d_pcm,
+                       static_cast<int16_t *>(h->d_in), d_desc, (long long)n_utt);
+    rc = launch(h, fixed, h->d_in, len, len, 1, 0, d_all, nullptr, F);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_rows_kernel<OutT>, dim3(blocks), dim3(256), 0, h->stream, d_all, d_out,
+                       d_desc + 3 * n_utt, (long long)n_utt, (int)ncep);
+    HIP_TRY(h, hipGetLastError());
+    return MFCC_HIP_SUCCESS;
 }
 
 template <typename OutT>
@@ -693,6 +758,18 @@ int mfcc_hip_process_ragged_i16(mfcc_hip_handle *h, const int16_t *pcm, const si
 int mfcc_hip_process_ragged_fixed_i16(mfcc_hip_handle *h, const int16_t *pcm, const size_t *offsets, size_t n_utt,
                                       int16_t *out, size_t cap, size_t *frame_offsets) {
     return process_ragged<int16_t>(h, true, pcm, offsets, n_utt, out, cap, frame_offsets);
+}
+
+int mfcc_hip_process_ragged_i16_dev(mfcc_hip_handle *h, const void *d_pcm, const size_t *offsets, size_t n_utt,
+                                    void *d_out, size_t cap, size_t *frame_offsets) {
+    return process_ragged_dev<float>(h, false, static_cast<const int16_t *>(d_pcm), offsets, n_utt,
+                                     static_cast<float *>(d_out), cap, frame_offsets);
+}
+
+int mfcc_hip_process_ragged_fixed_i16_dev(mfcc_hip_handle *h, const void *d_pcm, const size_t *offsets, size_t n_utt,
+                                          void *d_out, size_t cap, size_t *frame_offsets) {
+    return process_ragged_dev<int16_t>(h, true, static_cast<const int16_t *>(d_pcm), offsets, n_utt,
+                                       static_cast<int16_t *>(d_out), cap, frame_offsets);
 }
 
 int mfcc_hip_process_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t n, size_t stride, size_t nch,

@@ -433,6 +433,15 @@ def test_ragged_batch_is_bit_identical_to_per_utterance_calls(mfcc_amd, pad_mode
             assert np.array_equal(a, ra, equal_nan=True), len(u)
             assert np.array_equal(b, rb), len(u)
         assert m.process_batch([]) == []
+        # device-resident form: torch tensors in, views of one CUDA tensor out, same bits
+        import torch
+        dv = [torch.from_numpy(u).cuda() for u in utts]
+        dfl = m.process_batch(dv)
+        dfx = m.process_batch(dv, fixed=True)
+        torch.cuda.synchronize()
+        for a, b, da, db in zip(fl, fx, dfl, dfx):
+            assert da.is_cuda and np.array_equal(da.cpu().numpy(), a, equal_nan=True)
+            assert np.array_equal(db.cpu().numpy(), b)
     ref = mf.mfcc_float_ref(wav_pcm, pad_mode=pad_mode)
     e_max, e_l2 = _err(fl[-1], ref)
     assert e_max <= TOL and e_l2 <= TOL
