@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "codelets_gen.hpp"
+#include "fused_common.hpp"
 #include "kernels_generic.hpp"
 #include "tables.hpp"
 
@@ -59,8 +60,15 @@ constexpr int kNS1 = 4, kNS2 = 3;
 constexpr int kS1step[kNS1] = {0, 0, 1, 1}, kS1blk[kNS1] = {0, 1, 0, 1};
 constexpr int kS2step[kNS2] = {0, 0, 1}, kS2blk[kNS2] = {1, 2, 2};
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+using mfcc_fc::f32x4;
+using mfcc_fc::i32x4;
+using mfcc_fc::Cursor;
+using mfcc_fc::LaunchGeom;
+using mfcc_fc::Window;
+using mfcc_fc::advance;
+using mfcc_fc::window_of;
+using mfcc_fc::preemph8;
+using mfcc_fc::lds_barrier;
 using mfcc_codelets::v2f;
 
 struct Tables {
@@ -170,54 +178,12 @@ inline void bind_tables(const char *b, int n_cep, Tables &t) {
 
 // ---- device (helpers shared in spirit with kernel_fused512.hpp; kept local so the two kernels stay independent)
 
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 #define MFCC1K_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-struct Cursor {
-    int ch, t_in;
-    const int16_t *ptr;      // the tile's first sample
-};
-
-struct LaunchGeom {
-    int tiles_per_ch, n_ch, grid_div, grid_mod;
-    long long step_ptr, wrap_ptr;
-    int t_lo, t_hi;
-};
-
-__device__ __forceinline__ void advance(Cursor &c, const LaunchGeom &g) {
-    c.t_in += g.grid_mod;
-    c.ch += g.grid_div;
-    c.ptr += g.step_ptr;
-    if (c.t_in >= g.tiles_per_ch) {
-        c.t_in -= g.tiles_per_ch;
-        ++c.ch;
-        c.ptr += g.wrap_ptr;
-    }
-}
 
 struct Fetch {
     i32x4 v0, v1;
     int p0, p1;
 };
-
-struct Window {
-    const int16_t *ptr;
-    int t_in, shift;
-    bool inside;
-};
-
-__device__ __forceinline__ Window window_of(const Cursor &c, const LaunchGeom &g) {
-    Window w;
-    w.ptr = c.ptr;
-    w.t_in = c.t_in;
-    const int mis = (int)((reinterpret_cast<uintptr_t>(c.ptr) & 15) >> 1);
-    w.inside = c.t_in >= g.t_lo && c.t_in <= g.t_hi;
-    w.shift = w.inside ? mis : 0;
-    return w;
-}
 
 // fetcher u (0..447) takes pieces u and 448 + u (< 769) of the window, plus the dword in front of each
 __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch &f) {
@@ -246,24 +212,6 @@ __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const 
         f.p0 = mfcc_k::sample_at_i(s, base, first + 8 * u - 1) << 16;
         f.p1 = mfcc_k::sample_at_i(s, base, first + 8 * (kFetchers + u) - 1) << 16;
     }
-}
-
-// e[k] = 32 x[k] - 31 x[k-1] (exact; the 1/32 is in the window table), see kernel_fused512.hpp
-__device__ __forceinline__ void preemph8(int prev, const i32x4 &v, float *__restrict__ dst) {
-    const int c3132 = 0x0020ffe1;
-    float e[8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int before = m ? v[m - 1] : prev;
-        const int pe = (int)__builtin_amdgcn_alignbit((unsigned)v[m], (unsigned)before, 16u);
-        int e0, e1;
-        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e0) : "v"(pe), "s"(c3132));
-        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e1) : "v"(v[m]), "s"(c3132));
-        e[2 * m] = (float)e0;
-        e[2 * m + 1] = (float)e1;
-    }
-    reinterpret_cast<f32x4 *>(dst)[0] = (f32x4){e[0], e[1], e[2], e[3]};
-    reinterpret_cast<f32x4 *>(dst)[1] = (f32x4){e[4], e[5], e[6], e[7]};
 }
 
 __device__ __forceinline__ void park_window(float *Sf, int u, const Fetch &f) {

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "codelets_gen.hpp"
+#include "fused_common.hpp"
 #include "kernels_generic.hpp"
 #include "tables.hpp"
 
@@ -68,9 +69,16 @@ constexpr int kSUsed = 2 * 8 * kFetchers; // 3072 fp32 slots of the window (7 + 
 constexpr int kQWords = kWaves * 2 * 256;  // partial mel sums: [wave][block][lane*4]
 constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using mfcc_fc::f32x4;
+using mfcc_fc::i32x4;
+using mfcc_fc::Cursor;
+using mfcc_fc::LaunchGeom;
+using mfcc_fc::Window;
+using mfcc_fc::advance;
+using mfcc_fc::window_of;
+using mfcc_fc::preemph8;
+using mfcc_fc::lds_barrier;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FusedTables {
     const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 64 (pre-emphasis x32, real-FFT split x2)
@@ -202,13 +210,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup fence: it also
-// drains vmcnt, i.e. waits for the prefetch loads of the next tile and for role 0's output stores,
-// which nothing on the other side of the barrier depends on.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 #define MFCC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // Diagnostic build only (-DMFCC_FUSED_STAMPS): per-wave cycle sums of the phases of a tile, written
@@ -228,32 +229,6 @@ __device__ unsigned long long g_stamps[4 * 12 + 16];   // [wave][12 phases], the
 #define MFCC_STAMP(i) do {} while (0)
 #endif
 
-// Uniform (SGPR) cursor over the workgroup's tiles: tile = ch * tiles_per_ch + t_in.  Advancing by
-// the grid size is a handful of scalar adds with one carry -- no multiply or division in the loop
-// (a wave's scalar instructions issue ~10 clocks apart; the multiply form of this cost ~450 clocks
-// per tile in every wave).
-struct Cursor {
-    int ch, t_in;
-    const int16_t *ptr;      // the tile's first sample: s.pcm + ch * ch_stride + t_in * kTileHop
-};
-
-struct LaunchGeom {
-    int tiles_per_ch, n_ch, grid_div, grid_mod;      // grid = grid_div * tiles_per_ch + grid_mod
-    long long step_ptr, wrap_ptr;                    // samples: ptr step per grid stride / extra step on carry
-    int t_lo, t_hi;                                  // tiles t_lo <= t_in <= t_hi have their window inside the channel
-};
-
-__device__ __forceinline__ void advance(Cursor &c, const LaunchGeom &g) {
-    c.t_in += g.grid_mod;
-    c.ch += g.grid_div;
-    c.ptr += g.step_ptr;
-    if (c.t_in >= g.tiles_per_ch) {
-        c.t_in -= g.tiles_per_ch;
-        ++c.ch;
-        c.ptr += g.wrap_ptr;
-    }
-}
-
 // The tile's sample window: slot j stands for sample i = tile_first - shift + j of the channel,
 // j = 0..3071, where shift = 0..7 makes the 16-byte global loads aligned.  Fetcher u (0..191: the
 // lanes of roles 1..3; role 0 spends that time on the previous tile's tail) fetches the pieces
@@ -266,25 +241,6 @@ struct Fetch {
     i32x4 v0, v1;
     int p0, p1;          // dword in front of v0 / v1: its high half is the piece's predecessor sample
 };
-
-// uniform (scalar) geometry of a tile's window; every wave computes it, fetchers or not
-struct Window {
-    const int16_t *ptr;      // the tile's first sample
-    int t_in;
-    int shift;
-    bool inside;             // whole window (and the dword in front of it) lies inside the channel
-};
-
-__device__ __forceinline__ Window window_of(const Cursor &c, const LaunchGeom &g) {
-    Window w;
-    w.ptr = c.ptr;
-    w.t_in = c.t_in;
-    const int mis = (int)((reinterpret_cast<uintptr_t>(c.ptr) & 15) >> 1);   // samples past alignment
-    // t_lo / t_hi (host): first - 7 - 2 >= -halo (the dword in front of piece 0) and first + kSUsed <= n_samples
-    w.inside = c.t_in >= g.t_lo && c.t_in <= g.t_hi;
-    w.shift = w.inside ? mis : 0;
-    return w;
-}
 
 __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch &f) {
     if (w.inside) {
@@ -308,26 +264,6 @@ __device__ __forceinline__ void fetch_window(const mfcc_k::StreamDesc &s, const 
         f.p0 = mfcc_k::sample_at_i(s, base, first + 8 * u - 1) << 16;
         f.p1 = mfcc_k::sample_at_i(s, base, first + 8 * (kFetchers + u) - 1) << 16;
     }
-}
-
-// e[k] = 32 x[k] - 31 x[k-1] for the 8 samples packed in v, x[-1] = high half of prev.  One
-// v_dot2_i32_i16 per sample (the three-operand form: for the builtin hipcc picks v_dot2c, which costs
-// an extra v_mov 0 per sample); the 1/32 is in the window table.
-__device__ __forceinline__ void preemph8(int prev, const i32x4 &v, float *__restrict__ dst) {
-    const int c3132 = 0x0020ffe1;                  // (int16 -31, int16 32)
-    float e[8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int before = m ? v[m - 1] : prev;
-        const int pe = (int)__builtin_amdgcn_alignbit((unsigned)v[m], (unsigned)before, 16u);   // (x[2m-1], x[2m])
-        int e0, e1;
-        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e0) : "v"(pe), "s"(c3132));
-        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(e1) : "v"(v[m]), "s"(c3132));
-        e[2 * m] = (float)e0;
-        e[2 * m + 1] = (float)e1;
-    }
-    reinterpret_cast<f32x4 *>(dst)[0] = (f32x4){e[0], e[1], e[2], e[3]};
-    reinterpret_cast<f32x4 *>(dst)[1] = (f32x4){e[4], e[5], e[6], e[7]};
 }
 
 __device__ __forceinline__ void park_window(float *Sf, int u, const Fetch &f) {
