@@ -86,6 +86,7 @@ struct FusedTables {
     const float *a_mel;   // [4 waves][17][64] mel weights of the bins wave w transforms, in consumption order
     const float *a_extra; // [4 roles][8][64]  role 0: DCT rows; role 1: column-16 DFT + its mel weights
     int n_cep;
+    int n_mel;            // 32, or 16: block 1 does not exist (its zero sums must not reach the DCT as -inf * 0)
 };
 
 // ---- the mel contraction.  After pass 2, lane (j, g) of wave w holds |X|^2 of frame j at the 16
@@ -112,15 +113,18 @@ struct Sched<true> {
     static constexpr int blk[N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 };
 
+// 32 filters (every reference target) or 16 (the core's constructor default, mfcc.py:20): a 16-filter bank is
+// block 0 only -- it runs on the dense schedule with block 1's weights zero and its log-mel lanes masked
 inline bool supported(int nfft, int hop, int n_mel, int n_cep) {
-    return nfft == kNfft && hop == kHop && n_mel == kMel && n_cep >= 1 && n_cep <= kMaxCep;
+    return nfft == kNfft && hop == kHop && (n_mel == kMel || n_mel == 16) && n_cep >= 1 && n_cep <= n_mel;
 }
 
 // ---- host: constant tables in the exact order the kernel consumes them
 template <bool DENSE>
-inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep,
+inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep, int n_mel,
                          std::vector<char> &blob) {
     constexpr int kAmel = Sched<DENSE>::N;
+    if (n_mel != kMel && !DENSE) return false;
     using namespace mfcc_tables;
     std::vector<float> win(16 * 32), tw(16 * 16 * 2), amel(size_t(kWaves) * kAmel * 64, 0.0f),
         aext(size_t(kWaves) * kAextra * 64, 0.0f);
@@ -133,7 +137,11 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
             tw[(n2 * 16 + k1) * 2 + 0] = float(std::cos(a));
             tw[(n2 * 16 + k1) * 2 + 1] = float(std::sin(a));
         }
-    std::vector<double> md = mel_dense(kNfft, kMel, double(sample_rate));     // [32][257]
+    std::vector<double> md(size_t(kMel) * 257, 0.0);                          // [32][257], rows >= n_mel stay 0
+    {
+        std::vector<double> m0 = mel_dense(kNfft, n_mel, double(sample_rate));
+        std::copy(m0.begin(), m0.end(), md.begin());
+    }
     const double inv = 1.0 / (power_scale * power_scale);
     std::vector<char> covered(size_t(kMel) * 257, 0);
     auto M = [&](int wave, int idx, int lane) -> float & { return amel[(size_t(wave) * kAmel + idx) * 64 + lane]; };
@@ -152,13 +160,14 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         for (int idx = 0; idx < kAmel; ++idx) mel_op(wv, idx, Sched<DENSE>::blk[idx], Sched<DENSE>::k2[idx]);
     }
     // role 0 -- DCT rows: lane (coeff = l&15, g = l>>4) holds D[16 half + coeff][16 blk + 4 g + r]
-    std::vector<double> dd = dct_rows(n_cep, kMel, lifter);                    // [n_cep][32]
+    std::vector<double> dd = dct_rows(n_cep, n_mel, lifter);                   // [n_cep][n_mel]
     for (int half = 0; half < 2; ++half)
         for (int blk = 0; blk < 2; ++blk)
             for (int r = 0; r < 4; ++r)
                 for (int l = 0; l < 64; ++l) {
                     int coeff = 16 * half + (l & 15), filt = 16 * blk + 4 * (l >> 4) + r;
-                    E(0, 8 * half + 4 * blk + r, l) = coeff < n_cep ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
+                    E(0, 8 * half + 4 * blk + r, l) =
+                        (coeff < n_cep && filt < n_mel) ? float(dd[size_t(coeff) * n_mel + filt]) : 0.0f;
                 }
     // role 1 -- column 16: X[16 + 32 k2] = sum_n2 v[n2] W512^(n2 (16 + 32 k2)); MFMA row i = 4g + r:
     // r=0: Re k2=2g, r=1: Im k2=2g, r=2: Re k2=2g+1, r=3: Im k2=2g+1
@@ -190,7 +199,8 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     return true;
 }
 
-inline void bind_tables(const char *b, int n_cep, bool dense, FusedTables &t) {
+inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, FusedTables &t) {
+    t.n_mel = n_mel;
     const int kAmel = dense ? kAmelDense : kAmelBanded;
     // device pointer arithmetic only; layout = build_tables' put() order
     t.n_cep = n_cep;
@@ -273,7 +283,7 @@ __device__ __forceinline__ void park_window(float *Sf, int u, const Fetch &f) {
 
 // The summed mel energies of a finished tile, then log2 (MFCC.ipynb cell 36): register r of block b
 // is filter 16 b + 4 q + r of frame lo.
-__device__ __forceinline__ void mel_log2(const float *Qt, int lane, f32x4 &l0, f32x4 &l1) {
+__device__ __forceinline__ void mel_log2(const float *Qt, int lane, int n_mel, f32x4 &l0, f32x4 &l1) {
     const f32x4 *Q4 = reinterpret_cast<const f32x4 *>(Qt) + lane;
     const f32x4 m0 = (Q4[0 * 64] + Q4[2 * 64]) + (Q4[4 * 64] + Q4[6 * 64]);
     const f32x4 m1 = (Q4[1 * 64] + Q4[3 * 64]) + (Q4[5 * 64] + Q4[7 * 64]);
@@ -284,6 +294,7 @@ __device__ __forceinline__ void mel_log2(const float *Qt, int lane, f32x4 &l0, f
         l0[r] = __builtin_amdgcn_logf(m0[r]);
         l1[r] = __builtin_amdgcn_logf(m1[r]);
     }
+    if (n_mel <= 16) l1 = (f32x4){0.f, 0.f, 0.f, 0.f};          // no filters 16..31 (uniform)
 }
 
 // DCT-II (cells 38-39) and store: log-mel register r of block b == B[k = q][j = lo] of the DCT
@@ -439,7 +450,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             next_shift = wn.shift;
             if (role != 0) fetch_window(s, wn, fetcher, fx);
         }
-        if (role == 0 && have_prev) mel_log2(Qt, lane, lm0, lm1);
+        if (role == 0 && have_prev) mel_log2(Qt, lane, t.n_mel, lm0, lm1);
         MFCC_STAMP(6);
 
         // windowed real FFT-32 over n1, twiddled by W512^(n2 k1): columns 0..15 as (re, im) pairs, column 16
@@ -520,7 +531,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     }
     // the last tile of this workgroup
     if (role == 0 && have_prev) {
-        mel_log2(Qt, lane, lm0, lm1);
+        mel_log2(Qt, lane, t.n_mel, lm0, lm1);
         f32x4 d0 = zero, d1 = zero;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

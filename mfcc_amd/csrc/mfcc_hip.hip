@@ -218,10 +218,10 @@ int build_tables(mfcc_hip_handle *h) {
     h->fused_ok = false;
     h->fused_dense = false;
     if (mfcc_fused::supported(r.nfft, r.hop, r.n_mel, r.n_cep)) {
-        h->fused_ok = mfcc_fused::build_tables<false>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+        h->fused_ok = mfcc_fused::build_tables<false>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, r.n_mel, fused_blob);
         if (!h->fused_ok) {
             h->fused_dense = true;
-            h->fused_ok = mfcc_fused::build_tables<true>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, fused_blob);
+            h->fused_ok = mfcc_fused::build_tables<true>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, r.n_mel, fused_blob);
         }
     }
     size_t o_fu = 0;
@@ -260,7 +260,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.log2_dct = ilog2(4 * r.n_mel);
         h->xt.n_cep = r.n_cep;
     }
-    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, h->fused_dense, h->fu);
+    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, r.n_mel, h->fused_dense, h->fu);
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);

@@ -268,6 +268,23 @@ def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
 
 
+def test_constructor_defaults_16_filters_run_on_the_fused_kernel(mfcc_amd, wav_pcm):
+    """MFCC() = the core's constructor defaults (nfft 512, 16 filters, 16 coefficients, mfcc.py:20): a 16-filter
+    bank is block 0 of the dense schedule with block 1 masked."""
+    pcm = np.stack([wav_pcm[:40000], mf.synth_pcm(40000, seed=6)])
+    for ncep, pad in ((16, "notebook"), (5, "stream")):
+        ref = mf.mfcc_float_ref(pcm, n_cep=ncep, n_mel=16, pad_mode=pad)
+        with mfcc_amd.MFCC(nceptrums=ncep, pad_mode=pad) as m, mfcc_amd.MFCC(nceptrums=ncep, pad_mode=pad, impl="generic") as mg:
+            assert m.nfilters == 16 and m.kernel_name().endswith("fused512_kernel")
+            got = m.process(pcm)
+            gen = mg.process(pcm)
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        e_max, e_l2 = _err(got, ref)
+        assert e_max <= TOL and e_l2 <= TOL
+        e_max, e_l2 = _err(got, gen)
+        assert e_max <= 2e-5
+
+
 def test_float_linearity_property_full_size(mfcc_amd):
     """Size-independent property at config-2 size (10 min): scaling the input by 2 adds
     exactly 2*sqrt(32) to c0 (log2 of 4x power through the ortho DCT) and leaves c1.. unchanged."""
