@@ -6,7 +6,9 @@ with a stretch of silence, DC, full-scale square, pure sine).  Fixed contract: t
 kernel against oracle/mfcc_fixed.py, bit for bit.  Float contract: the fused 512 and 1024 kernels against
 the generic kernel (5e-5 of the largest coefficient; DC / square / sine inputs have mel bands at the fp32
 noise floor where two fp32 FFTs legitimately differ after the log -- DESIGN.md section 1 -- so they are
-reported, not counted, unless FUZZ_STRICT is set).  FUZZ_FIXED=1 restricts the run to the fixed contract."""
+reported, not counted, unless FUZZ_STRICT is set; the same holds above 22.05 kHz, where the first mel
+filter sits on the DC bin that pre-emphasis empties).  The fused 512 kernel also gets random sample rates
+and 16-filter banks.  FUZZ_FIXED=1 restricts the run to the fixed contract."""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch, mfcc_amd
@@ -83,8 +85,12 @@ while time.time() - t0 < budget:
                     ref = mx.mfcc_fixed_ref(x, nceptrums=ncep, pad_mode=pad); ok = np.array_equal(got[c], ref)
                 if not ok: fails += 1; print("FIXED MISMATCH", tag, c); break
         else:
-            kw = dict(nfft=nfft, nfilters=32 if cfg == "f512" else 40, nceptrums=ncep, pad_mode=pad,
+            nmel = (16 if rng.random() < 0.25 else 32) if cfg == "f512" else 40
+            sr = int(rng.choice([16000, 16000, 8000, 22050, 44100, 48000])) if cfg == "f512" else 16000
+            kw = dict(nfft=nfft, nfilters=nmel, nceptrums=min(ncep, nmel), pad_mode=pad, samplerate=sr,
                       power_scale=512.0 if cfg == "f512" else 0)
+            tag = tag + (nmel, sr)
+            noisy = noisy or sr > 22050          # the first mel filter degenerates to the (emptied) DC bin
             with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
                 ga = a.process(view, halo=halo).cpu().numpy(); gb = b.process(view, halo=halo).cpu().numpy()
             ok, why = close(ga, gb, 5e-5)
