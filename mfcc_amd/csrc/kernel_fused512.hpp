@@ -27,13 +27,17 @@
 //          they meet in the LDS tile Q.  One wave ("role 1") also turns column 16 into bins 16+32j
 //          with a 16x16 real DFT matrix (4 MFMAs) and feeds them (4 MFMAs).  Another ("role 0")
 //          finishes the PREVIOUS tile in this window: log2 of the summed mel energies, DCT-II as 8
-//          MFMAs whose B operand IS the mel accumulator layout (K index permuted, no lane movement),
-//          store n_cep floats per frame.  Nobody waits for that tail.
+//          MFMAs (16 for n_cep > 16) whose B operand IS the mel accumulator layout (K index permuted,
+//          no lane movement), interleaved with its mel MFMAs; store n_cep floats per frame.  Nobody
+//          waits for that tail.
 //  ---- workgroup barrier B2 ----
 //
+// Two instantiations: the BANDED MFMA list above is the mel matrix at 16 kHz; DENSE issues all 32
+// (k2, block) pairs and serves every other sample rate and the 16-filter bank (struct Sched).
+//
 // HBM traffic per frame: 170 new int16 samples + 13 floats out = 392 B (plus the 342-sample overlap
-// between consecutive tiles, 11 %).  The kernel is bound by the CU's VALU and LDS pipes (about 9 k
-// lane-ops and 8 KB of LDS traffic per frame), not by HBM; DESIGN.md has the accounting.
+// between consecutive tiles, 11 %).  The kernel is bound by the CU's VALU and LDS pipes (86 VALU
+// wave-instructions and 8 KB of LDS traffic per frame), not by HBM; DESIGN.md has the accounting.
 #pragma once
 
 #include <hip/hip_runtime.h>
