@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MFCC_HIP_ABI_VERSION 1
+#define MFCC_HIP_ABI_VERSION 2
 
 /* error codes: same numbering family as `enum ft601_error` (software/ft601.h:25-32) */
 enum mfcc_hip_error {
@@ -212,6 +212,50 @@ int  mfcc_hip_convert_wav(mfcc_hip_handle *h, const char *wav_in, const char *mf
  * n_files calls of mfcc_hip_convert_wav.  n_frames_each (n_files entries) may be NULL. */
 int  mfcc_hip_convert_wavs(mfcc_hip_handle *h, const char *const *wav_in, const char *const *mfcc_out,
                            size_t n_files, int fixed, size_t *n_frames_each);
+
+/* ---- online / streaming session: the core's real interface is a stream with state --------------
+ * `MFCC.sink` (samples in), `MFCC.source` (coefficients out, one `first..last` burst per frame) and
+ * `MFCC.reset` (mfcc/core/mfcc.py:28-30,116); the targets feed it chunk by chunk
+ * (mfcc/targets/wav2mfcc.py:27-42: bit 31 of a word = soft reset; mic2mfcc.py:19-30: I2S samples
+ * through a FIFO) and the receiver reads columns as they come (software/cepstrum.c:93-159).
+ * A session carries exactly the core's cross-frame state on the device between calls: the one
+ * pre-emphasis history sample (preemph.py:20-28) and the samples of the frame in progress (the ring
+ * buffer of frame.py:65-153, at most nfft - 1 + hop of them).  Any chunking of a stream gives, frame
+ * for frame, bit for bit, the result of the one-shot calls above (tests/test_gpu_parity.py).
+ * Several sessions may share a handle; like the handle they are not thread-safe.                 */
+typedef struct mfcc_hip_stream mfcc_hip_stream;
+
+/* fixed = 0: float contract (out = float), fixed = 1: RTL contract (out = int16_t) */
+int  mfcc_hip_stream_create(mfcc_hip_handle *h, int fixed, mfcc_hip_stream **out);
+void mfcc_hip_stream_destroy(mfcc_hip_stream *s);
+/* `mfcc_softreset` (software/main.c:21-34): drop the pending samples, history back to 0 */
+int  mfcc_hip_stream_reset(mfcc_hip_stream *s);
+/* samples waiting for their frame to complete (0 <= pending < nfft between calls) */
+size_t mfcc_hip_stream_pending(const mfcc_hip_stream *s);
+/* upper bound of the frames a push of n samples can complete: (pending + n) / hop + 1 */
+size_t mfcc_hip_stream_max_frames(const mfcc_hip_stream *s, size_t n);
+/*
+ * Feed n samples (host buffer); every frame they complete is computed and written to `out`
+ * ([frames][n_cep], float or int16_t by the session's contract; out_capacity in elements).
+ * *n_frames_out = frames written (may be 0).  MFCC_HIP_ERROR_BUFFER_SMALL leaves the session
+ * untouched.  Synchronous.
+ */
+int  mfcc_hip_stream_push(mfcc_hip_stream *s, const int16_t *samples, size_t n, void *out,
+                          size_t out_capacity, size_t *n_frames_out);
+/*
+ * End of the stream.  MFCC_HIP_PAD_STREAM: the host driver keeps feeding zeros until the frame
+ * holding the last sample is out (main.c:134-144) -- one more, zero-padded frame is written.
+ * MFCC_HIP_PAD_NOTEBOOK: the tail samples are dropped (notebook cell 9), nothing is written.
+ * Either way the session is back in its reset state afterwards.
+ */
+int  mfcc_hip_stream_flush(mfcc_hip_stream *s, void *out, size_t out_capacity, size_t *n_frames_out);
+
+/* ---- `.mfcc` -> `.lift` (software/lift.py:28-40): host only, no GPU --------------------------
+ * reads raw int16 [frame][n_cep], multiplies column n by 1 + (L/2) sin(pi n / L) in double
+ * (lift.py:12-26; L <= 0: unchanged) and writes `astype(np.int16)` of it: truncation toward zero,
+ * low 16 bits for values beyond int16 (what NumPy does on x86-64).  *n_frames_out may be NULL. */
+int  mfcc_hip_lift_file(const char *mfcc_in, const char *lift_out, int n_cep, double L,
+                        size_t *n_frames_out);
 
 /* ---- serial wire format of the FPGA's coefficient stream (host only, no GPU) ---------------
  * mfcc/misc/magic.py:9-41 (MagicInserter: 0xa55a in front of every frame's coefficients),

@@ -7,9 +7,9 @@ in ``libmfcc_hip.so``; importing this package needs the library to be built (no 
 """
 from ._lib import MfccHipError, LIB_PATH, load as load_library  # noqa: F401
 from . import wire  # noqa: F401  (serial wire format + power gate, software/serial.c, cepstrum.c)
-from .api import (MFCC, PAD_NOTEBOOK, PAD_STREAM, get_table, lifter, make_params, mfcc_close,  # noqa: F401
-                  mfcc_convert, mfcc_open, num_frames, show_dir_content)
+from .api import (MFCC, MfccStream, PAD_NOTEBOOK, PAD_STREAM, get_table, lift_file, lifter,  # noqa: F401
+                  make_params, mfcc_close, mfcc_convert, mfcc_open, num_frames, show_dir_content)
 
-__all__ = ["MFCC", "mfcc_open", "mfcc_convert", "mfcc_close", "show_dir_content", "lifter",
+__all__ = ["MFCC", "MfccStream", "lift_file", "mfcc_open", "mfcc_convert", "mfcc_close", "show_dir_content", "lifter",
            "num_frames", "get_table", "make_params", "MfccHipError", "load_library",
            "PAD_NOTEBOOK", "PAD_STREAM", "wire"]

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmfcc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum mfcc_hip_error
 SUCCESS = 0
@@ -97,6 +97,14 @@ SYMBOLS = {
                                     C.POINTER(C.c_float)]),
     "mfcc_hip_kernel_name": (C.c_char_p, [_H, C.c_int]),
     "mfcc_hip_convert_wav": (C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_int, _PSZ]),
+    "mfcc_hip_stream_create": (C.c_int, [_H, C.c_int, C.POINTER(_H)]),
+    "mfcc_hip_stream_destroy": (None, [_H]),
+    "mfcc_hip_stream_reset": (C.c_int, [_H]),
+    "mfcc_hip_stream_pending": (C.c_size_t, [_H]),
+    "mfcc_hip_stream_max_frames": (C.c_size_t, [_H, _SZ]),
+    "mfcc_hip_stream_push": (C.c_int, [_H, C.c_void_p, _SZ, C.c_void_p, _SZ, _PSZ]),
+    "mfcc_hip_stream_flush": (C.c_int, [_H, C.c_void_p, _SZ, _PSZ]),
+    "mfcc_hip_lift_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_double, _PSZ]),
 }
 
 _lib = None

@@ -103,6 +103,15 @@ class MFCC:
                                    lifter=lifter, device=device, impl=impl)
         self.hop = self._params.hop or self.nfft // 3
         h = C.c_void_p()
+        self._device_index = None
+        if int(device) < 0:
+            # "the current device" is resolved NOW, by the library, from torch's current device
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    self._device_index = torch.cuda.current_device()
+            except ImportError:
+                pass
         _lib.check(self._lib.mfcc_hip_create(C.byref(self._params), C.byref(h)), "mfcc_hip_create")
         self._h = h
 
@@ -173,17 +182,50 @@ class MFCC:
         if pcm.stride(1) != 1:
             pcm = pcm.contiguous()
         nch, n_tot = pcm.shape
+        if halo not in (0, 1) or n_tot < int(halo):
+            raise ValueError("halo must be 0 or 1 and counted in the samples")
         n = n_tot - int(halo)
         nf = self.num_frames(n)
+        self._check_device(pcm)
+        odt = torch.int16 if fixed else torch.float32
         if out is None:
-            out = torch.empty((nch, nf, self.nceptrums), device=pcm.device,
-                              dtype=torch.int16 if fixed else torch.float32)
-        self.set_stream(torch.cuda.current_stream(pcm.device).cuda_stream)
+            out = torch.empty((nch, nf, self.nceptrums), device=pcm.device, dtype=odt)
+        else:
+            # the kernel gets raw pointers: a wrong shape / dtype / layout / device would be an out-of-bounds write
+            want = (nf, self.nceptrums) if squeeze and out.dim() == 2 else (nch, nf, self.nceptrums)
+            if tuple(out.shape) != want or out.dtype != odt or not out.is_contiguous() or out.device != pcm.device:
+                raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (odt, want, pcm.device))
         fn = self._lib.mfcc_hip_process_fixed_i16_dev if fixed else self._lib.mfcc_hip_process_i16_dev
         got = C.c_size_t(0)
-        _lib.check(fn(self._h, C.c_void_p(pcm.data_ptr()), n, pcm.stride(0), nch, int(halo),
-                      C.c_void_p(out.data_ptr()), C.byref(got)), "process_dev")
-        return out[0] if squeeze else out
+        with self._on_torch_stream(pcm.device):
+            _lib.check(fn(self._h, C.c_void_p(pcm.data_ptr()), n, pcm.stride(0), nch, int(halo),
+                          C.c_void_p(out.data_ptr()), C.byref(got)), "process_dev")
+        if squeeze and out.dim() == 3:
+            return out[0]
+        return out
+
+    def _check_device(self, t):
+        """The handle's tables, stream and scratch live on ONE GPU: refuse tensors of another one."""
+        if self._device_index is None:
+            import torch
+            self._device_index = torch.cuda.current_device() if self._params.device < 0 else int(self._params.device)
+        if t.device.index != self._device_index:
+            raise ValueError("tensor on %s but this MFCC handle was created on cuda:%d" % (t.device, self._device_index))
+
+    def _on_torch_stream(self, device):
+        """Context: launch on torch's current stream of `device`, then go back to the handle's own stream, so
+        that later host-path calls do not run on (or outlive) a stream torch owns."""
+        import contextlib
+        import torch
+
+        @contextlib.contextmanager
+        def ctx():
+            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            try:
+                yield
+            finally:
+                self.use_own_stream()
+        return ctx()
 
     def process(self, pcm, halo=0, out=None):
         """Float contract: int16 PCM ``(n,)`` / ``(channels, n)`` -> float32 ``(.., frames, nceptrums)``.
@@ -238,10 +280,11 @@ class MFCC:
         nf = sum(self.num_frames(u.numel()) for u in utts)
         out = torch.empty((nf, self.nceptrums), device=utts[0].device, dtype=torch.int16 if fixed else torch.float32)
         fo = np.zeros(n + 1, dtype=np.uint64)
-        self.set_stream(torch.cuda.current_stream(utts[0].device).cuda_stream)
+        self._check_device(flat)
         fn = self._lib.mfcc_hip_process_ragged_fixed_i16_dev if fixed else self._lib.mfcc_hip_process_ragged_i16_dev
-        _lib.check(fn(self._h, C.c_void_p(flat.data_ptr()), offsets.ctypes.data_as(C.c_void_p), n,
-                      C.c_void_p(out.data_ptr()), out.numel(), fo.ctypes.data_as(C.c_void_p)), "process_ragged_dev")
+        with self._on_torch_stream(flat.device):
+            _lib.check(fn(self._h, C.c_void_p(flat.data_ptr()), offsets.ctypes.data_as(C.c_void_p), n,
+                          C.c_void_p(out.data_ptr()), out.numel(), fo.ctypes.data_as(C.c_void_p)), "process_ragged_dev")
         assert int(fo[-1]) == nf
         return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
 
@@ -250,12 +293,19 @@ class MFCC:
         import torch
         if pcm.dim() == 1:
             pcm = pcm[None, :]
-        self.set_stream(torch.cuda.current_stream(pcm.device).cuda_stream)
+        self._check_device(pcm)
         ms = C.c_float(0)
-        _lib.check(self._lib.mfcc_hip_time_dev(self._h, int(fixed), C.c_void_p(pcm.data_ptr()), pcm.shape[1],
-                                               pcm.stride(0), pcm.shape[0], C.c_void_p(out.data_ptr()),
-                                               warmup, iters, C.byref(ms)), "time_dev")
+        with self._on_torch_stream(pcm.device):
+            _lib.check(self._lib.mfcc_hip_time_dev(self._h, int(fixed), C.c_void_p(pcm.data_ptr()), pcm.shape[1],
+                                                   pcm.stride(0), pcm.shape[0], C.c_void_p(out.data_ptr()),
+                                                   warmup, iters, C.byref(ms)), "time_dev")
         return float(ms.value)
+
+
+    # -- online mode: the core's own interface, sink / source / reset (mfcc/core/mfcc.py:28-30) -----
+    def stream(self, fixed=False) -> "MfccStream":
+        """A streaming session on this handle: feed chunks, get the frames they complete."""
+        return MfccStream(self, fixed)
 
     # -- file level: mfcc_convert(sess, path_in, path_out), software/main.c:100-177 -----
     def convert_many(self, paths_in, paths_out, fixed=True):
@@ -274,6 +324,72 @@ class MFCC:
         _lib.check(self._lib.mfcc_hip_convert_wav(self._h, os.fsencode(path_in), os.fsencode(path_out),
                                                   int(fixed), C.byref(nf)), "convert %s" % path_in)
         return int(nf.value)
+
+
+class MfccStream:
+    """Online mode -- the stream interface of the nMigen core (``sink`` in, ``source`` out, ``reset``;
+    mfcc/core/mfcc.py:28-30,116) and of its targets (wav2mfcc.py:27-42: bit 31 = soft reset; mic2mfcc.py:19-30).
+    The session keeps the core's cross-frame state on the device: one pre-emphasis history sample and the
+    samples of the frame in progress.  Any chunking gives the one-shot result, frame for frame, bit for bit."""
+
+    def __init__(self, mfcc: MFCC, fixed=False):
+        self._m = mfcc
+        self._lib = mfcc._lib
+        self.fixed = bool(fixed)
+        s = C.c_void_p()
+        _lib.check(self._lib.mfcc_hip_stream_create(mfcc._h, int(self.fixed), C.byref(s)), "stream_create")
+        self._s = s
+
+    def close(self):
+        if getattr(self, "_s", None) and getattr(self._m, "_h", None):
+            self._lib.mfcc_hip_stream_destroy(self._s)
+        self._s = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def pending(self) -> int:
+        return int(self._lib.mfcc_hip_stream_pending(self._s))
+
+    def _out(self, nf):
+        return np.empty((nf, self._m.nceptrums), dtype=np.int16 if self.fixed else np.float32)
+
+    def push(self, samples) -> np.ndarray:
+        """``sink``: int16 samples in; returns the ``(frames, nceptrums)`` they complete (possibly 0 rows)."""
+        samples = np.ascontiguousarray(samples)
+        if samples.dtype != np.int16 or samples.ndim != 1:
+            raise TypeError("samples must be a 1-D int16 array (the core's sink is signed 16 bit, mfcc.py:29)")
+        out = self._out(int(self._lib.mfcc_hip_stream_max_frames(self._s, samples.size)))
+        nf = C.c_size_t(0)
+        _lib.check(self._lib.mfcc_hip_stream_push(self._s, samples.ctypes.data, samples.size, out.ctypes.data,
+                                                  out.size, C.byref(nf)), "stream_push")
+        return out[:nf.value]
+
+    def flush(self) -> np.ndarray:
+        """End of the stream: the zero-padded tail frame of the host driver (main.c:134-144) with
+        ``pad_mode="stream"``, nothing with ``"notebook"``; the session is reset afterwards."""
+        out = self._out(1)
+        nf = C.c_size_t(0)
+        _lib.check(self._lib.mfcc_hip_stream_flush(self._s, out.ctypes.data, out.size, C.byref(nf)), "stream_flush")
+        return out[:nf.value]
+
+    def reset(self):
+        """``MFCC.reset`` / ``mfcc_softreset`` (main.c:21-34): drop pending samples, history back to 0."""
+        _lib.check(self._lib.mfcc_hip_stream_reset(self._s), "stream_reset")
+
+
+def lift_file(mfcc_in, lift_out, nceptrums=32, L=22) -> int:
+    """``x.mfcc -> x.lift`` like the loop of software/lift.py:28-40 (host only); returns the frame count."""
+    nf = C.c_size_t(0)
+    _lib.check(_lib.load().mfcc_hip_lift_file(os.fsencode(mfcc_in), os.fsencode(lift_out), int(nceptrums), float(L),
+                                              C.byref(nf)), "lift_file %s" % mfcc_in)
+    return int(nf.value)
 
 
 # ---- software/main.c names ---------------------------------------------------------------

@@ -106,6 +106,8 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         }
     const int nb = kNfft / 2 + 1;                                             // 513
     std::vector<double> md = mel_dense(kNfft, kMel, double(sample_rate));     // [40][513]
+    for (int f = 0; f < kMel; ++f)
+        if (md[size_t(f) * nb] != 0.0) return false;      // weight on the DC bin: the generic kernel sums it in double
     const double inv = 1.0 / (power_scale * power_scale);
     std::vector<char> covered(size_t(kMel) * nb, 0);
     auto Wt = [&](int filt, int bin) -> double { return filt < kMel ? md[size_t(filt) * nb + bin] * inv : 0.0; };

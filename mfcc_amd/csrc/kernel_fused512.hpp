@@ -72,6 +72,13 @@ constexpr int kFetchers = 192;            // threads that fetch and park the sam
 constexpr int kSUsed = 2 * 8 * kFetchers; // 3072 fp32 slots of the window (7 + 15 * 170 + 512 = 3069 are read)
 constexpr int kQWords = kWaves * 2 * 256;  // partial mel sums: [wave][block][lane*4]
 constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed;
+// DCX instantiation only (a mel filter with weight on bin 0, see FusedTables::win_dc): the double-precision
+// window rows [16 n2][32 n1] at a row stride of 34 doubles (lane n2 reads 16 bytes at 272 n2 + 16 i: the 16
+// lanes of a ds_read_b128 group cover all 64 banks), and the per-lane partial sums [16 frames][16 n2] at a
+// row stride of 17 doubles (lane j reads row j pair by pair: 34 j mod 64 are 16 distinct bank pairs)
+constexpr int kWdRow = 34;
+constexpr int kDcRow = 17;
+constexpr int kDcxWords = 2 * (16 * kWdRow + kTile * kDcRow);
 
 using mfcc_fc::f32x4;
 using mfcc_fc::i32x4;
@@ -89,6 +96,12 @@ struct FusedTables {
     const float2 *tw;     // [16 n2][16 k1]   W512^(n2 k1)
     const float *a_mel;   // [4 waves][17][64] mel weights of the bins wave w transforms, in consumption order
     const float *a_extra; // [4 roles][8][64]  role 0: DCT rows; role 1: column-16 DFT + its mel weights
+    const double *win_dc; // [16 n2][32 n1]   hamming[16 n1 + n2] / 32 in double -- or nullptr.  Set when a mel filter has
+                          // weight on bin 0 (any sample rate whose first two filter points are both 0: 44.1 kHz, 48 kHz ...).
+                          // X[0] = sum w e is REAL: it comes arbitrarily close to 0 by cancellation, the log turns its
+                          // relative error into an absolute one, and an fp32 sum is then off by 1e-6 rms / |X[0]|
+                          // (measured: 2.2 in log2 units at |X[0]| = 5e-6 rms, profiles/r02_dc_band.json) -- so bin 0
+                          // alone is accumulated in double (every other bin is complex and does not cancel that way)
     int n_cep;
     int n_mel;            // 32, or 16: block 1 does not exist (its zero sums must not reach the DCT as -inf * 0)
 };
@@ -124,6 +137,14 @@ inline bool supported(int nfft, int hop, int n_mel, int n_cep) {
 }
 
 // ---- host: constant tables in the exact order the kernel consumes them
+// true when some filter of the bank has weight on the (real-valued) DC bin
+inline bool needs_dc_exact(int sample_rate, int n_mel) {
+    std::vector<double> m0 = mfcc_tables::mel_dense(kNfft, n_mel, double(sample_rate));
+    for (int f = 0; f < n_mel; ++f)
+        if (m0[size_t(f) * 257] != 0.0) return true;
+    return false;
+}
+
 template <bool DENSE>
 inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep, int n_mel,
                          std::vector<char> &blob) {
@@ -200,10 +221,17 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     };
     blob.clear();
     put(win); put(tw); put(amel); put(aext);
+    // double-precision window rows for the DC bin (8-byte aligned: everything before is a multiple of 8 bytes)
+    std::vector<double> wd(16 * 32);
+    for (int n2 = 0; n2 < 16; ++n2)
+        for (int n1 = 0; n1 < 32; ++n1) wd[n2 * 32 + n1] = w[16 * n1 + n2] / 32.0;
+    size_t off = blob.size();
+    blob.resize(off + wd.size() * 8);
+    std::memcpy(blob.data() + off, wd.data(), wd.size() * 8);
     return true;
 }
 
-inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, FusedTables &t) {
+inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, bool dc_exact, FusedTables &t) {
     t.n_mel = n_mel;
     const int kAmel = dense ? kAmelDense : kAmelBanded;
     // device pointer arithmetic only; layout = build_tables' put() order
@@ -212,7 +240,8 @@ inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, FusedTa
     t.win = f;                  f += 16 * 32;
     t.tw = reinterpret_cast<const float2 *>(f); f += 16 * 16 * 2;
     t.a_mel = f;                f += kWaves * kAmel * 64;
-    t.a_extra = f;
+    t.a_extra = f;              f += kWaves * kAextra * 64;
+    t.win_dc = dc_exact ? reinterpret_cast<const double *>(f) : nullptr;
 }
 
 // ---- device
@@ -366,11 +395,11 @@ __device__ __forceinline__ void mel_dct_steps(const float (&am)[Sched<DENSE>::N]
     }
 }
 
-template <bool DENSE>
+template <bool DENSE, bool DCX>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
     constexpr int kAmel = Sched<DENSE>::N;
-    __shared__ __attribute__((aligned(16))) float lds[kLdsWords];
+    __shared__ __attribute__((aligned(16))) float lds[kLdsWords + (DCX ? kDcxWords : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,6 +414,11 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     float *const Vt = Tt + kTile * kTFrame;                        // [16 frames][18]
     float *const Qt = Vt + kTile * kVStride;                       // [4 waves][2 blocks][256]
     float *const Sf = Qt + kQWords;                                // pre-emphasised sample window, fp32
+    double *const Wd = reinterpret_cast<double *>(Sf + kSUsed);    // DCX: double window rows, [16][kWdRow]
+    double *const Dc = Wd + 16 * kWdRow;                           // DCX: partial DC sums, [16 frames][kDcRow]
+    if constexpr (DCX) {
+        for (int i = tid; i < 16 * 32; i += 64 * kWaves) Wd[(i >> 5) * kWdRow + (i & 31)] = t.win_dc[i];
+    }
 
     // per-lane constants, resident for the whole kernel
     using mfcc_codelets::v2f;
@@ -443,6 +477,20 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
         }
+        if constexpr (DCX) {
+            // bin 0 of this lane's 32 samples in double: sum_n1 w[16 n1 + n2] e[16 n1 + n2] (the products of a
+            // 24-bit window value and a 22-bit integer are exact in double; so is their sum to 2^-53)
+            const double *wr = Wd + lo * kWdRow;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; m += 2) {
+                a0 = __builtin_fma(wr[2 * m + 0], (double)ep[m][0], a0);
+                a1 = __builtin_fma(wr[2 * m + 1], (double)ep[m][1], a1);
+                a2 = __builtin_fma(wr[2 * m + 2], (double)ep[m + 1][0], a2);
+                a3 = __builtin_fma(wr[2 * m + 3], (double)ep[m + 1][1], a3);
+            }
+            Dc[fr_id * kDcRow + lo] = (a0 + a1) + (a2 + a3);
+        }
         // next tile's samples fly while this tile is processed; role 0 picks up the previous tile's
         // mel sums instead (behind the sample reads in the LDS queue)
         const Cursor me = cur;
@@ -484,6 +532,19 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             mfcc_codelets::cfft16(x, z);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
+        }
+        if constexpr (DCX) {
+            if (wave == 0) {                     // lanes (frame lo, k1 = 0) hold bin 0 in pw[0]
+                const double *dr = Dc + lo * kDcRow;
+                double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2 += 2) {
+                    x0 += dr[n2];
+                    x1 += dr[n2 + 1];
+                }
+                x0 += x1;
+                if (q == 0) pw[0] = (float)(x0 * x0);
+            }
         }
         MFCC_STAMP(2);
 
@@ -557,6 +618,7 @@ inline const char *kernel_name() { return "mfcc_fused512_kernel"; }
 // returns false when the problem does not fit the kernel's 32-bit tile arithmetic
 inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense, float *out, int n_cu,
                    hipStream_t stream) {
+    const bool dcx = t.win_dc != nullptr;        // only ever set together with the dense schedule
     const long long tiles_per_ch = (s.frames_per_ch + kTile - 1) / kTile;
     const long long n_ch = s.total_frames / s.frames_per_ch;
     const long long n_tiles = tiles_per_ch * n_ch;
@@ -575,10 +637,12 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense
     if (g.t_lo < 0) g.t_lo = 0;
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
-    if (dense)
-        hipLaunchKernelGGL(mfcc_fused512_kernel<true>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    if (dense && dcx)
+        hipLaunchKernelGGL((mfcc_fused512_kernel<true, true>), dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    else if (dense)
+        hipLaunchKernelGGL((mfcc_fused512_kernel<true, false>), dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
     else
-        hipLaunchKernelGGL(mfcc_fused512_kernel<false>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
+        hipLaunchKernelGGL((mfcc_fused512_kernel<false, false>), dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out);
     return true;
 }
 

@@ -51,6 +51,8 @@ struct FloatTables {
     const int    *mel_off;    // [n_mel] offset into mel_w
     const float  *mel_w;      // packed weights, 1/power_scale^2 folded in
     const float  *dct;        // [n_cep][n_mel] (lifter folded in)
+    const double *window_d;   // [NFFT] the window in double, or nullptr: set when a mel filter has weight on bin 0 --
+                              // that bin is then accumulated in double (kernel_fused512.hpp, FusedTables::win_dc)
     int n_mel, n_cep;
 };
 
@@ -100,6 +102,15 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             // y[0] = x[0] for the very first sample of a stream: history is 0 there
             float y = x0 - 0.96875f * x1;
             za[i] = y * t.window[i];
+        }
+        double dc = 0.0;
+        if (t.window_d) {                       // uniform: X[0] = sum w y in double (y is exact)
+            for (int i = lane; i < NFFT; i += 64) {
+                const double yd = (double)sample_at_i(s, base, n0 + i) - 0.96875 * (double)sample_at_i(s, base, n0 + i - 1);
+                dc = __builtin_fma(t.window_d[i], yd, dc);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dc += __shfl_xor(dc, o, 64);
         }
         wave_sync();
 
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             float2 w = t.tw_split[k];
             float xr = er + (w.x * orr - w.y * oi);
             float xi = ei + (w.x * oi + w.y * orr);
-            P[k] = xr * xr + xi * xi;
+            P[k] = (k == 0 && t.window_d) ? (float)(dc * dc) : xr * xr + xi * xi;
         }
         wave_sync();
 

@@ -119,12 +119,26 @@ struct mfcc_hip_handle {
     mfcc_fused::FusedTables fu{};
     mfcc_fixed512::Tables x5{};
     mfcc_fused1024::Tables f1k{};
-    std::vector<long long> ragged_desc;   // descriptor table of the last asynchronous ragged call (its H2D copy source)
-    // scratch for the host-buffer entry points
+    // descriptor tables of the ragged calls live in pinned host memory, two buffers used in turn: the H2D copy of
+    // an asynchronous call reads buffer i while the next call fills buffer 1 - i; the call after that waits for the
+    // event recorded behind buffer i's copy before it overwrites it
+    struct PinnedDesc {
+        long long *p = nullptr;
+        size_t cap = 0;
+        hipEvent_t copied = nullptr;
+        bool in_flight = false;
+    } desc[2];
+    int desc_next = 0;
+    // scratch for the host-buffer and ragged entry points.  It is reused by calls that may run on different
+    // streams (mfcc_hip_set_stream): scratch_done is recorded behind every use and the next use on ANOTHER stream
+    // waits for it on the device (an event outlives the stream it was recorded on)
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
 };
 
 namespace {
@@ -137,6 +151,56 @@ namespace {
             return e__ == hipErrorOutOfMemory ? MFCC_HIP_ERROR_NO_MEM : MFCC_HIP_ERROR_OTHER; \
         }                                        \
     } while (0)
+
+// Makes h's device current for the scope and puts the caller's device back afterwards (a process that drives
+// several GPUs -- torch included -- must not find its current device changed by a library call).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// order a new use of the handle's scratch buffers behind the previous one when the stream has changed
+int scratch_acquire(mfcc_hip_handle *h) {
+    if (h->scratch_used && h->scratch_stream != h->stream)
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->scratch_done, 0));
+    return MFCC_HIP_SUCCESS;
+}
+
+int scratch_release(mfcc_hip_handle *h) {
+    HIP_TRY(h, hipEventRecord(h->scratch_done, h->stream));
+    h->scratch_stream = h->stream;
+    h->scratch_used = true;
+    return MFCC_HIP_SUCCESS;
+}
+
+// a pinned descriptor buffer of at least n entries that no copy in flight still reads
+int desc_acquire(mfcc_hip_handle *h, size_t n, mfcc_hip_handle::PinnedDesc **out) {
+    mfcc_hip_handle::PinnedDesc &d = h->desc[h->desc_next];
+    h->desc_next ^= 1;
+    if (d.in_flight) {
+        HIP_TRY(h, hipEventSynchronize(d.copied));
+        d.in_flight = false;
+    }
+    if (d.cap < n) {
+        if (d.p) HIP_TRY(h, hipHostFree(d.p));
+        d.p = nullptr;
+        d.cap = 0;
+        const size_t want = n + n / 2 + 64;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&d.p), want * sizeof(long long), hipHostMallocDefault));
+        d.cap = want;
+    }
+    if (!d.copied) HIP_TRY(h, hipEventCreateWithFlags(&d.copied, hipEventDisableTiming));
+    *out = &d;
+    return MFCC_HIP_SUCCESS;
+}
 
 struct Arena {
     std::vector<char> host;
@@ -175,6 +239,9 @@ int build_tables(mfcc_hip_handle *h) {
     std::vector<double> dd = dct_rows(r.n_cep, r.n_mel, r.lifter);
     std::vector<float> dct(dd.begin(), dd.end());
 
+    bool dc_exact = false;                     // some filter has weight on the real-valued DC bin: that bin in double
+    for (int f = 0; f < r.n_mel; ++f) dc_exact = dc_exact || md[size_t(f) * (M + 1)] != 0.0;
+    size_t o_wd = dc_exact ? a.put(wd) : 0;
     size_t o_win = a.put(win), o_twf = a.put(twf), o_tws = a.put(tws);
     size_t o_ms = a.put(ms.start), o_mc = a.put(ms.count), o_mo = a.put(ms.off);
     size_t o_mw = a.put(melw), o_dct = a.put(dct);
@@ -217,8 +284,11 @@ int build_tables(mfcc_hip_handle *h) {
     std::vector<char> fused_blob;
     h->fused_ok = false;
     h->fused_dense = false;
+    bool fused_dcx = false;
     if (mfcc_fused::supported(r.nfft, r.hop, r.n_mel, r.n_cep)) {
-        h->fused_ok = mfcc_fused::build_tables<false>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, r.n_mel, fused_blob);
+        fused_dcx = mfcc_fused::needs_dc_exact(r.sample_rate, r.n_mel);    // only the dense instantiation has the DC path
+        h->fused_ok = !fused_dcx &&
+                      mfcc_fused::build_tables<false>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, r.n_mel, fused_blob);
         if (!h->fused_ok) {
             h->fused_dense = true;
             h->fused_ok = mfcc_fused::build_tables<true>(r.sample_rate, r.power_scale, r.lifter, r.n_cep, r.n_mel, fused_blob);
@@ -243,6 +313,7 @@ int build_tables(mfcc_hip_handle *h) {
     h->ft.mel_off = reinterpret_cast<const int *>(b + o_mo);
     h->ft.mel_w = reinterpret_cast<const float *>(b + o_mw);
     h->ft.dct = reinterpret_cast<const float *>(b + o_dct);
+    h->ft.window_d = dc_exact ? reinterpret_cast<const double *>(b + o_wd) : nullptr;
     h->ft.n_mel = r.n_mel;
     h->ft.n_cep = r.n_cep;
     if (h->fixed_ok) {
@@ -260,7 +331,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.log2_dct = ilog2(4 * r.n_mel);
         h->xt.n_cep = r.n_cep;
     }
-    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, r.n_mel, h->fused_dense, h->fu);
+    if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, r.n_mel, h->fused_dense, fused_dcx, h->fu);
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
@@ -301,7 +372,7 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
     s.total_frames = (long long)(nf * nch);
     s.hop = h->r.hop;
 
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const long long total = s.total_frames;
     if (fixed && h->fixed512_ok) {
         mfcc_fixed512::launch(s, h->x5, static_cast<int16_t *>(d_out), h->n_cu, h->stream);
@@ -325,6 +396,14 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         if (blocks > cap) blocks = cap;
         float *o = static_cast<float *>(d_out);
         switch (h->r.nfft) {
+            case 64:
+                hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<64>, dim3((unsigned)blocks),
+                                   dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
+                break;
+            case 128:
+                hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<128>, dim3((unsigned)blocks),
+                                   dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
+                break;
             case 256:
                 hipLaunchKernelGGL(mfcc_k::mfcc_float_generic_kernel<256>, dim3((unsigned)blocks),
                                    dim3(mfcc_k::kBlock), 0, h->stream, s, h->ft, o);
@@ -368,16 +447,18 @@ int process_host(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, size_t n, s
     if (nf == 0 || nch == 0) return MFCC_HIP_SUCCESS;
     const size_t n_out = nf * nch * size_t(h->r.n_cep);
     if (!out || cap < n_out) return MFCC_HIP_ERROR_BUFFER_SMALL;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t in_bytes = n * nch * sizeof(int16_t);
     int rc = ensure(h, &h->d_in, &h->d_in_bytes, in_bytes + 64);
     if (rc) return rc;
     rc = ensure(h, &h->d_out, &h->d_out_bytes, n_out * sizeof(OutT));
     if (rc) return rc;
+    if ((rc = scratch_acquire(h))) return rc;
     if (in_bytes) HIP_TRY(h, hipMemcpyAsync(h->d_in, pcm, in_bytes, hipMemcpyHostToDevice, h->stream));
     rc = launch(h, fixed, h->d_in, n, n, nch, 0, h->d_out, nullptr);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, h->d_out, n_out * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = scratch_release(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MFCC_HIP_SUCCESS;
 }
@@ -415,8 +496,12 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     if (!h || !offsets || !frame_offsets) return MFCC_HIP_ERROR_INVALID_PARAM;
     if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
     const size_t hop = size_t(h->r.hop), nfft = size_t(h->r.nfft), ncep = size_t(h->r.n_cep);
-    std::vector<long long> &desc = h->ragged_desc; // [0, 3n): pack descriptors, [3n, 6n): row-gather descriptors; kept
-    desc.assign(6 * n_utt, 0);                     // alive in the handle: the H2D copy below is asynchronous
+    DeviceGuard guard(h->device);
+    mfcc_hip_handle::PinnedDesc *pd = nullptr;     // [0, 3n): pack descriptors, [3n, 6n): row-gather descriptors, in
+    int rc = desc_acquire(h, 6 * n_utt, &pd);      // pinned memory: the H2D copy below is asynchronous
+    if (rc) return rc;
+    long long *desc = pd->p;
+    for (size_t i = 0; i < 6 * n_utt; ++i) desc[i] = 0;
     size_t pos = 0, total = 0;
     frame_offsets[0] = 0;
     for (size_t u = 0; u < n_utt; ++u) {
@@ -440,16 +525,19 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     if (total == 0) return MFCC_HIP_SUCCESS;
     if (!d_out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
     const size_t F = pos / hop, len = pos + nfft + hop;
-    HIP_TRY(h, hipSetDevice(h->device));
-    int rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
+    const size_t desc_bytes = 6 * n_utt * sizeof(long long);
+    rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
     if (rc) return rc;
-    rc = ensure(h, &h->d_out, &h->d_out_bytes, F * ncep * sizeof(OutT) + desc.size() * sizeof(long long) + 64);
+    rc = ensure(h, &h->d_out, &h->d_out_bytes, F * ncep * sizeof(OutT) + desc_bytes + 64);
     if (rc) return rc;
+    if ((rc = scratch_acquire(h))) return rc;
     OutT *d_all = static_cast<OutT *>(h->d_out);
     const size_t desc_off = (F * ncep * sizeof(OutT) + 7) & ~size_t(7);
     long long *d_desc = reinterpret_cast<long long *>(static_cast<char *>(h->d_out) + desc_off);
     HIP_TRY(h, hipMemsetAsync(h->d_in, 0, len * sizeof(int16_t), h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_desc, desc, desc_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(pd->copied, h->stream));
+    pd->in_flight = true;
     const unsigned blocks = (unsigned)std::min<size_t>(n_utt, size_t(h->n_cu) * 8);
     hipLaunchKernelGGL(pack_utterances_kernel, dim3(blocks), dim3(256), 0, h->stream, d_pcm,
                        static_cast<int16_t *>(h->d_in), d_desc, (long long)n_utt);
@@ -458,7 +546,7 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     hipLaunchKernelGGL(gather_rows_kernel<OutT>, dim3(blocks), dim3(256), 0, h->stream, d_all, d_out,
                        d_desc + 3 * n_utt, (long long)n_utt, (int)ncep);
     HIP_TRY(h, hipGetLastError());
-    return MFCC_HIP_SUCCESS;
+    return scratch_release(h);
 }
 
 template <typename OutT>
@@ -491,11 +579,12 @@ int process_ragged(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, const siz
     if (!out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
     const size_t F = pos / hop;                              // frames of the packed stream
     const size_t len = pos + nfft + hop;                     // its samples (zeros behind the last utterance)
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     int rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
     if (rc) return rc;
     rc = ensure(h, &h->d_out, &h->d_out_bytes, (F + total) * ncep * sizeof(OutT) + desc.size() * sizeof(long long) + 64);
     if (rc) return rc;
+    if ((rc = scratch_acquire(h))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_in, 0, len * sizeof(int16_t), h->stream));
     for (size_t u = 0; u < n_utt; ++u) {
         const size_t n = offsets[u + 1] - offsets[u];
@@ -516,7 +605,8 @@ int process_ragged(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, const siz
                        (long long)n_utt, (int)ncep);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, d_dense, total * ncep * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((rc = scratch_release(h))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // also: `desc` (pageable, on this stack) is consumed
     return MFCC_HIP_SUCCESS;
 }
 
@@ -695,13 +785,19 @@ int mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out) {
         mfcc_hip_destroy(h);
         return code;
     };
-    if (hipSetDevice(dev) != hipSuccess) return fail(MFCC_HIP_ERROR_NOT_FOUND);
+    DeviceGuard guard(dev);
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != dev) return fail(MFCC_HIP_ERROR_NOT_FOUND);
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(MFCC_HIP_ERROR_OTHER);
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         return fail(MFCC_HIP_ERROR_OTHER);
     h->stream = h->own_stream;
+    if (hipEventCreateWithFlags(&h->scratch_done, hipEventDisableTiming) != hipSuccess)
+        return fail(MFCC_HIP_ERROR_OTHER);
     rc = build_tables(h);
     if (rc) return fail(rc);
     if (r.float_impl == MFCC_HIP_IMPL_FUSED512 && !h->fused_ok) return fail(MFCC_HIP_ERROR_UNSUPPORTED);
@@ -711,10 +807,19 @@ int mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out) {
 
 void mfcc_hip_destroy(mfcc_hip_handle *h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
+    if (h->scratch_used) (void)hipEventSynchronize(h->scratch_done);     // scratch may be in use on a caller's stream
     if (h->own_stream) {
         (void)hipStreamSynchronize(h->own_stream);
         (void)hipStreamDestroy(h->own_stream);
+    }
+    if (h->scratch_done) (void)hipEventDestroy(h->scratch_done);
+    for (auto &d : h->desc) {
+        if (d.copied) {
+            if (d.in_flight) (void)hipEventSynchronize(d.copied);
+            (void)hipEventDestroy(d.copied);
+        }
+        if (d.p) (void)hipHostFree(d.p);
     }
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_in) (void)hipFree(h->d_in);
@@ -785,25 +890,29 @@ int mfcc_hip_process_fixed_i16_dev(mfcc_hip_handle *h, const void *d_pcm, size_t
 int mfcc_hip_time_dev(mfcc_hip_handle *h, int fixed, const void *d_pcm, size_t n, size_t stride,
                       size_t nch, void *d_out, int warmup, int iters, float *avg_ms) {
     if (!h || iters < 1 || warmup < 0 || !avg_ms) return MFCC_HIP_ERROR_INVALID_PARAM;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     for (int i = 0; i < warmup; ++i) {
         int rc = launch(h, fixed != 0, d_pcm, n, stride, nch, 0, d_out, nullptr);
         if (rc) return rc;
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    struct Events {                                // destroyed on every return path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    HIP_TRY(h, hipEventCreate(&ev.e0));
+    HIP_TRY(h, hipEventCreate(&ev.e1));
+    HIP_TRY(h, hipEventRecord(ev.e0, h->stream));
     for (int i = 0; i < iters; ++i) {
         int rc = launch(h, fixed != 0, d_pcm, n, stride, nch, 0, d_out, nullptr);
         if (rc) return rc;
     }
-    HIP_TRY(h, hipEventRecord(e1, h->stream));
-    HIP_TRY(h, hipEventSynchronize(e1));
+    HIP_TRY(h, hipEventRecord(ev.e1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(ev.e1));
     float ms = 0.0f;
-    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(h, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *avg_ms = ms / float(iters);
     return MFCC_HIP_SUCCESS;
 }
@@ -893,6 +1002,189 @@ int mfcc_hip_convert_wavs(mfcc_hip_handle *h, const char *const *wav_in, const c
         if (wr != want) return MFCC_HIP_ERROR_IO;
         if (n_frames_each) n_frames_each[i] = nf;
     }
+    return MFCC_HIP_SUCCESS;
+}
+
+// ---- online / streaming session (include/mfcc_hip.h: mfcc_hip_stream_*) -----------------------------------
+// Device buffer layout, both ping-pong buffers: [0] = the history sample x[first - 1] (0 after reset),
+// [1 .. 1 + pending) = the samples of the frame in progress, then the new samples of this push.
+
+}  // extern "C"
+
+struct mfcc_hip_stream {
+    mfcc_hip_handle *h = nullptr;
+    bool fixed = false;
+    int16_t *buf[2] = {nullptr, nullptr};
+    size_t cap = 0;                 // samples each buffer holds behind the history slot
+    int cur = 0;                    // buffer that holds history + pending
+    size_t pending = 0;
+    void *d_out = nullptr;
+    size_t d_out_bytes = 0;
+};
+
+namespace {
+
+int stream_reserve(mfcc_hip_stream *s, size_t samples, size_t out_bytes) {
+    mfcc_hip_handle *h = s->h;
+    if (samples > s->cap) {
+        const size_t want = samples + samples / 2 + 4096;
+        int16_t *nb[2] = {nullptr, nullptr};
+        for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&nb[i]), (want + 1 + 64) * sizeof(int16_t)));
+        // carry history + pending over (the other buffer holds nothing that is still needed)
+        HIP_TRY(h, hipMemsetAsync(nb[0], 0, sizeof(int16_t), h->stream));
+        if (s->buf[s->cur])
+            HIP_TRY(h, hipMemcpyAsync(nb[0], s->buf[s->cur], (1 + s->pending) * sizeof(int16_t), hipMemcpyDeviceToDevice,
+                                      h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (s->buf[i]) (void)hipFree(s->buf[i]);
+            s->buf[i] = nb[i];
+        }
+        s->cur = 0;
+        s->cap = want;
+    }
+    if (out_bytes > s->d_out_bytes) {
+        if (s->d_out) HIP_TRY(h, hipFree(s->d_out));
+        s->d_out = nullptr;
+        s->d_out_bytes = 0;
+        const size_t want = out_bytes + out_bytes / 2 + 4096;
+        HIP_TRY(h, hipMalloc(&s->d_out, want));
+        s->d_out_bytes = want;
+    }
+    return MFCC_HIP_SUCCESS;
+}
+
+// run `nf` frames over history + the first `total` samples of the current buffer, copy them to `out`
+int stream_emit(mfcc_hip_stream *s, size_t total, size_t nf, void *out) {
+    mfcc_hip_handle *h = s->h;
+    const size_t esz = s->fixed ? sizeof(int16_t) : sizeof(float);
+    const size_t bytes = nf * size_t(h->r.n_cep) * esz;
+    int rc = launch(h, s->fixed, s->buf[s->cur], total, total + 1, 1, /*halo=*/1, s->d_out, nullptr, nf);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, s->d_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    return MFCC_HIP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mfcc_hip_stream_create(mfcc_hip_handle *h, int fixed, mfcc_hip_stream **out) {
+    if (!h || !out) return MFCC_HIP_ERROR_INVALID_PARAM;
+    *out = nullptr;
+    if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
+    mfcc_hip_stream *s = new (std::nothrow) mfcc_hip_stream();
+    if (!s) return MFCC_HIP_ERROR_NO_MEM;
+    s->h = h;
+    s->fixed = fixed != 0;
+    DeviceGuard guard(h->device);
+    int rc = stream_reserve(s, size_t(h->r.nfft) * 8, size_t(64) * size_t(h->r.n_cep) * sizeof(float));
+    if (rc) {
+        mfcc_hip_stream_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return MFCC_HIP_SUCCESS;
+}
+
+void mfcc_hip_stream_destroy(mfcc_hip_stream *s) {
+    if (!s) return;
+    DeviceGuard guard(s->h->device);
+    (void)hipStreamSynchronize(s->h->stream);
+    for (int i = 0; i < 2; ++i)
+        if (s->buf[i]) (void)hipFree(s->buf[i]);
+    if (s->d_out) (void)hipFree(s->d_out);
+    delete s;
+}
+
+int mfcc_hip_stream_reset(mfcc_hip_stream *s) {
+    if (!s) return MFCC_HIP_ERROR_INVALID_PARAM;
+    DeviceGuard guard(s->h->device);
+    s->pending = 0;
+    HIP_TRY(s->h, hipMemsetAsync(s->buf[s->cur], 0, sizeof(int16_t), s->h->stream));     // history := 0
+    HIP_TRY(s->h, hipStreamSynchronize(s->h->stream));
+    return MFCC_HIP_SUCCESS;
+}
+
+size_t mfcc_hip_stream_pending(const mfcc_hip_stream *s) { return s ? s->pending : 0; }
+
+size_t mfcc_hip_stream_max_frames(const mfcc_hip_stream *s, size_t n) {
+    return s ? (s->pending + n) / size_t(s->h->r.hop) + 1 : 0;
+}
+
+int mfcc_hip_stream_push(mfcc_hip_stream *s, const int16_t *samples, size_t n, void *out, size_t cap,
+                         size_t *n_frames_out) {
+    if (!s || (n && !samples)) return MFCC_HIP_ERROR_INVALID_PARAM;
+    mfcc_hip_handle *h = s->h;
+    const size_t nfft = size_t(h->r.nfft), hop = size_t(h->r.hop), ncep = size_t(h->r.n_cep);
+    const size_t total = s->pending + n;
+    const size_t nf = total >= nfft ? (total - nfft) / hop + 1 : 0;          // frames this push completes
+    if (n_frames_out) *n_frames_out = nf;
+    if (nf && (!out || cap < nf * ncep)) return MFCC_HIP_ERROR_BUFFER_SMALL;  // nothing consumed yet
+    DeviceGuard guard(h->device);
+    int rc = stream_reserve(s, total, nf * ncep * sizeof(float));
+    if (rc) return rc;
+    if (n)
+        HIP_TRY(h, hipMemcpyAsync(s->buf[s->cur] + 1 + s->pending, samples, n * sizeof(int16_t), hipMemcpyHostToDevice,
+                                  h->stream));
+    if (nf) {
+        rc = stream_emit(s, total, nf, out);
+        if (rc) return rc;
+        // the next frame starts nf hops further on: its history sample and what is already there move to the
+        // front of the other buffer
+        const size_t used = nf * hop;
+        HIP_TRY(h, hipMemcpyAsync(s->buf[s->cur ^ 1], s->buf[s->cur] + used, (1 + total - used) * sizeof(int16_t),
+                                  hipMemcpyDeviceToDevice, h->stream));
+        s->cur ^= 1;
+        s->pending = total - used;
+    } else {
+        s->pending = total;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // `samples` and `out` belong to the caller again
+    return MFCC_HIP_SUCCESS;
+}
+
+int mfcc_hip_stream_flush(mfcc_hip_stream *s, void *out, size_t cap, size_t *n_frames_out) {
+    if (!s) return MFCC_HIP_ERROR_INVALID_PARAM;
+    mfcc_hip_handle *h = s->h;
+    const size_t nf = h->r.pad_mode == MFCC_HIP_PAD_STREAM ? 1 : 0;
+    if (n_frames_out) *n_frames_out = nf;
+    if (nf && (!out || cap < size_t(h->r.n_cep))) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    DeviceGuard guard(h->device);
+    if (nf) {
+        // the zero-padded tail frame of main.c:134-144: the pending samples, then zeros (the kernels read
+        // x[i] = 0 beyond the `total` samples they are given)
+        int rc = stream_emit(s, s->pending, 1, out);
+        if (rc) return rc;
+    }
+    return mfcc_hip_stream_reset(s);
+}
+
+int mfcc_hip_lift_file(const char *mfcc_in, const char *lift_out, int n_cep, double L, size_t *n_frames_out) {
+    if (!mfcc_in || !lift_out || n_cep <= 0) return MFCC_HIP_ERROR_INVALID_PARAM;
+    FILE *f = std::fopen(mfcc_in, "rb");
+    if (!f) return MFCC_HIP_ERROR_IO;
+    std::vector<int16_t> v;
+    int16_t buf[4096];
+    size_t got;
+    while ((got = std::fread(buf, sizeof(int16_t), 4096, f)) > 0) v.insert(v.end(), buf, buf + got);
+    std::fclose(f);
+    if (v.size() % size_t(n_cep)) return MFCC_HIP_ERROR_INVALID_PARAM;       // np.reshape(raw, (-1, NCEPSTRUMS)) would raise
+    std::vector<double> lift(n_cep, 1.0);
+    if (L > 0.0)
+        for (int n = 0; n < n_cep; ++n) lift[n] = 1.0 + (L / 2.0) * std::sin(mfcc_tables::kPi * double(n) / L);
+    for (size_t i = 0; i < v.size(); ++i) {
+        // lift.py:39: (lift * cepstra).astype(np.int16) -- truncation toward zero; a value beyond int16 keeps
+        // its low 16 bits (C conversion through a wider integer, what NumPy does on x86-64)
+        const double x = lift[i % size_t(n_cep)] * double(v[i]);
+        v[i] = int16_t(uint16_t(int64_t(x)));
+    }
+    FILE *o = std::fopen(lift_out, "wb");
+    if (!o) return MFCC_HIP_ERROR_IO;
+    const size_t wr = v.empty() ? 0 : std::fwrite(v.data(), sizeof(int16_t), v.size(), o);
+    std::fclose(o);
+    if (wr != v.size()) return MFCC_HIP_ERROR_IO;
+    if (n_frames_out) *n_frames_out = v.size() / size_t(n_cep);
     return MFCC_HIP_SUCCESS;
 }
 

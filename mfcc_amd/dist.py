@@ -80,12 +80,36 @@ def process_frames_sharded(compute: Callable, pcm: np.ndarray, rank: int, world:
 
     ``compute(samples, halo, n_frames)`` must return ``n_frames`` rows for frames that start at
     ``samples[halo]``, treating ``samples[0]`` as history when ``halo == 1`` and zero-padding
-    past the end (``MFCC.process(..., halo=1)`` on the device path does exactly this)."""
+    past the end -- :func:`mfcc_compute` wraps a real :class:`mfcc_amd.MFCC` handle into that shape."""
     shard = plan_frames(len(pcm), world, nfft, hop, n_frames)[rank]
     if shard.n_frames == 0:
         return shard, np.zeros((0, n_cep), dtype=np.float32)
     out = compute(pcm[shard.sample_lo:shard.sample_hi], shard.halo, shard.n_frames)
     return shard, np.asarray(out)
+
+
+def mfcc_compute(m, fixed: bool = False, device=None) -> Callable:
+    """The ``compute`` callback of :func:`process_frames_sharded` for a real ``MFCC`` handle ``m``:
+    moves the shard to the GPU, runs ``m.process`` / ``m.process_fixed`` with the history halo, trims to the
+    shard's frame count and returns a NumPy array.
+
+    Trimming matters with ``pad_mode="stream"``: a non-final shard run through a STREAM handle yields one extra
+    zero-padded tail frame that belongs to nobody (the final shard's last frame IS the stream's padded tail,
+    because its sample span ends at the end of the stream)."""
+    import torch
+
+    def compute(samples, halo, n_frames):
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        x = torch.as_tensor(np.ascontiguousarray(samples, dtype=np.int16)).to(dev)
+        need = (n_frames - 1) * m.hop + m.nfft + int(halo)
+        if x.numel() < need and m.num_frames(x.numel() - int(halo)) < n_frames:
+            # the zero-padded tail of a STREAM plan run through a NOTEBOOK handle: pad explicitly
+            x = torch.cat([x, torch.zeros(need - x.numel(), dtype=torch.int16, device=dev)])
+        out = m.process_fixed(x, halo=halo) if fixed else m.process(x, halo=halo)
+        assert out.shape[0] >= n_frames, (out.shape, n_frames)
+        return out[:n_frames].cpu().numpy()
+
+    return compute
 
 
 def gather_frames(local, n_cep: int, group=None, dst: Optional[int] = None):

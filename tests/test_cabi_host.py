@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_params_struct():
     lib = L.load()
-    assert lib.mfcc_hip_abi_version() == 1
+    assert lib.mfcc_hip_abi_version() == 2
     p = L.Params()
     assert lib.mfcc_hip_default_params(C.byref(p)) == 0
     assert p.struct_size == C.sizeof(L.Params) == 64

@@ -1,0 +1,155 @@
+"""The DC-only mel band at 44.1 / 48 kHz (round-1 soak: 22 fused-vs-generic mismatches, gpurun_out/soak2.log).
+
+At those rates the first two filter points are both 0 (notebook cell 27, filterbank.py:15-20), so filter 0 is
+the DC bin alone.  X[0] = sum w[n] y[n] is REAL: for noise it is a zero-mean Gaussian that comes arbitrarily
+close to 0, the log turns the relative error of that sum into an absolute error of the log-mel value, and an
+fp32 sum is off by about 1e-6 rms / |X[0]| (measured with the round-1 kernels: 2.2 in log2 units at
+|X[0]| = 5e-6 rms, both kernels alike; profiles/r02_dc_band.json).  Both float kernels therefore accumulate
+bin 0 -- and only bin 0 -- in double whenever a filter has weight on it.  These tests compare BOTH kernels with
+the float64 oracle band by band (with all 32 coefficients the DCT is orthonormal, so log-mel = c . D), on the
+shapes the soak logged and on inputs built to cancel the DC bin."""
+import numpy as np
+import pytest
+
+from oracle import mfcc_float as mf
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+D32 = mf.dct_basis(32, 32)
+
+
+@pytest.fixture(scope="module")
+def mfcc_amd():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import mfcc_amd
+    return mfcc_amd
+
+
+def _both(mfcc_amd, x, sr, **kw):
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, **kw) as a, \
+         mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, impl="generic", **kw) as b:
+        assert a.kernel_name().endswith("fused512_kernel") and b.kernel_name().endswith("generic_kernel")
+        return a.process(x).astype(np.float64), b.process(x).astype(np.float64)
+
+
+def _signal(rng, n, kind):
+    if kind == "g30":
+        x = rng.standard_normal(n) * 30
+    elif kind == "g3000":
+        x = rng.standard_normal(n) * 3000
+    elif kind == "g12000":
+        x = rng.standard_normal(n) * 12000
+    elif kind == "uniform":
+        x = rng.integers(-32768, 32768, n).astype(np.float64)
+    else:                                            # noise with a stretch of silence
+        x = rng.standard_normal(n) * 3000
+        a, b = sorted(rng.integers(0, n + 1, 2))
+        x[a:b] = 0
+    return np.clip(x, -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("sr", [44100, 48000])
+def test_filter_points_put_filter_0_on_the_dc_bin(sr):
+    pts, _ = mf.get_filter_points(0, sr / 2, 32, 512, sample_rate=sr)
+    assert pts[0] == 0 and pts[1] == 0 and pts[2] == 1
+    f = mf.get_filters(pts, 512)
+    assert f[0, 0] == 1.0 and np.count_nonzero(f[0]) == 1
+
+
+@pytest.mark.parametrize("sr", [44100, 48000])
+@pytest.mark.parametrize("kind", ["g30", "g3000", "uniform"])
+def test_both_kernels_match_the_float64_oracle_band_by_band(mfcc_amd, sr, kind):
+    """40 000 frames per case.  Round-1 kernels: band-0 log-mel error up to 2.2, coefficient error up to 1.5e-2 of
+    the largest coefficient.  Now band 0 is as good as the other bands."""
+    rng = np.random.default_rng(5)
+    x = _signal(rng, 512 + 170 * 39999, kind)
+    ga, gb = _both(mfcc_amd, x, sr)
+    ref, st = mf.mfcc_notebook(x, sample_rate=sr, return_stages=True)
+    lm = st["logmel"]
+    cmax = np.abs(ref).max()
+    for name, g in (("fused", ga), ("generic", gb)):
+        assert np.abs(g - ref).max() / cmax <= TOL, (name, np.abs(g - ref).max() / cmax)
+        err = np.abs(g @ D32 - lm)                   # per-band log-mel error
+        assert err[:, 0].max() < 2e-3, (name, err[:, 0].max())           # the DC band: ~1e-5 measured
+        assert err[:, 1:].max() < 5e-2, (name, err[:, 1:].max())         # single complex bins: chi-square tails
+
+
+# (channels, samples, halo, pad_mode, n_cep, stride, offset, sample rate) of soak2.log's mismatches, incl. the one
+# with a `finite pattern` difference and the largest one (0.0534 of 65.9); the soak printed no per-case seed, so the
+# signal kinds it drew (Gaussian at three levels / uniform / partly silent) are all run on every shape
+SOAK2 = [
+    (1, 1427, 0, "notebook", 22, 1432, 1, 48000),
+    (1, 23235, 0, "notebook", 10, 23241, 2, 44100),
+    (2, 18487, 0, "notebook", 5, 18493, 3, 48000),
+    (2, 21743, 1, "stream", 10, 21746, 6, 44100),
+    (4, 5881, 1, "stream", 4, 5883, 2, 48000),
+]
+
+
+@pytest.mark.parametrize("shape", SOAK2)
+def test_soak2_shapes_against_the_oracle(mfcc_amd, shape):
+    import torch
+    nch, n, halo, pad, ncep, stride, off, sr = shape
+    rng = np.random.default_rng(n)
+    for kind in ("g30", "g3000", "g12000", "uniform", "silence"):
+        flat = np.zeros(off + stride * nch + 16, dtype=np.int16)
+        for c in range(nch):
+            flat[off + c * stride: off + c * stride + n + halo] = _signal(rng, n + halo, kind)
+        view = torch.as_strided(torch.from_numpy(flat).cuda(), (nch, n + halo), (stride, 1), storage_offset=off)
+        kw = dict(nfft=512, nfilters=32, nceptrums=ncep, samplerate=sr, pad_mode=pad)
+        with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
+            ga = a.process(view, halo=halo).cpu().numpy().astype(np.float64)
+            gb = b.process(view, halo=halo).cpu().numpy().astype(np.float64)
+        for c in range(nch):
+            x = flat[off + c * stride: off + c * stride + n + halo]
+            if halo:            # the oracle has no halo argument: put the shard one hop into a longer stream
+                ref = mf.mfcc_float_ref(np.concatenate([np.zeros(169, np.int16), x]), n_cep=ncep, sample_rate=sr,
+                                        pad_mode=pad)[1:]
+            else:
+                ref = mf.mfcc_float_ref(x, n_cep=ncep, sample_rate=sr, pad_mode=pad)
+            for name, g in (("fused", ga[c]), ("generic", gb[c])):
+                g = g[:len(ref)]
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(g), fin), (name, kind, c, "finite pattern")
+                assert np.array_equal(g[~fin], ref[~fin], equal_nan=True), (name, kind, c, "-inf pattern")
+                if fin.any():
+                    e = np.abs(g[fin] - ref[fin]).max() / max(np.abs(ref[fin]).max(), 1.0)
+                    assert e <= TOL, (name, kind, c, e)
+
+
+@pytest.mark.parametrize("sr", [44100, 48000])
+def test_frames_built_to_cancel_the_dc_bin(mfcc_amd, sr):
+    """Worst case by construction: frames whose DC bin is made to cancel to 1e-10 .. 1e-6 of its rms by adjusting
+    a few samples (greedy integer search on the float64 sum).  An fp32 sum cannot resolve these (its own rounding
+    is 1e-7 rms); the double sum does, so both kernels still agree with the notebook to 1e-4."""
+    rng = np.random.default_rng(11)
+    w = mf.hamming_window(512)
+    c = np.append(w[:-1] - 0.96875 * w[1:], w[-1])           # X[0] = sum c[n] x[n] for a frame with history 0
+    rms = np.sqrt((c ** 2).sum()) * 3000
+    frames = []
+    for _ in range(64):
+        x = np.clip(rng.standard_normal(512) * 3000, -20000, 20000).astype(np.int64)
+        x = x - np.round(np.dot(c, x) * c / np.dot(c, c)).astype(np.int64)       # coarse: remove the projection on c
+        s = float(np.dot(c, x))                                                    # fine: two samples, 300 random tries
+        j, k, d1 = rng.integers(0, 512, 300), rng.integers(0, 512, 300), rng.integers(-40, 41, 300)
+        r = s - d1 * c[j]
+        d2 = np.round(r / c[k])
+        res = np.abs(r - d2 * c[k])
+        res[(j == k) | (np.abs(d2) > 3000)] = np.inf
+        i = int(np.argmin(res))
+        x[j[i]] -= d1[i]
+        x[k[i]] -= int(d2[i])
+        assert np.abs(x).max() < 32768
+        frames.append(x)
+    # one utterance per frame: every cancelling frame is frame 0 of its own stream (history 0)
+    utts = [np.ascontiguousarray(f.astype(np.int16)) for f in frames]
+    dc = np.array([abs(float(np.dot(c, f))) for f in frames])
+    assert 1e-10 < np.median(dc / rms) < 1e-6 and dc.min() > 0
+    ref = np.stack([mf.mfcc_float_ref(u, n_cep=32, sample_rate=sr)[0] for u in utts])
+    for impl in ("auto", "generic"):
+        with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, impl=impl) as m:
+            got = np.stack([r[0] for r in m.process_batch(utts)]).astype(np.float64)
+        lm_err = np.abs(got @ D32 - ref @ D32)
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= TOL, (impl, np.abs(got - ref).max())
+        assert lm_err[:, 0].max() < 1e-2, (impl, lm_err[:, 0].max(), (dc / rms).min())

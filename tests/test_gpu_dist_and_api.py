@@ -1,0 +1,76 @@
+"""The real MFCC handle wired into mfcc_amd.dist's frame-range sharding (every shard of every plan on one GPU),
+small float transforms on the generic kernel, and the argument checks of the device path."""
+import numpy as np
+import pytest
+
+from oracle import mfcc_fixed as mx
+from oracle import mfcc_float as mf
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mfcc_amd():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import mfcc_amd
+    return mfcc_amd
+
+
+@pytest.mark.parametrize("pad_mode", ["notebook", "stream"])
+@pytest.mark.parametrize("fixed", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_every_frame_shard_through_the_real_handle(mfcc_amd, wav_pcm, pad_mode, fixed, world):
+    """plan_frames -> mfcc_compute(MFCC) per rank -> concatenation == the unsharded result, bit for bit
+    (one-sample history halo; a non-final shard of a STREAM handle drops its spurious tail frame)."""
+    from mfcc_amd import dist as md
+    pcm = wav_pcm[:170 * 501 + 512 + 37]
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode=pad_mode) as m:
+        whole = m.process_fixed(pcm) if fixed else m.process(pcm)
+        nf = m.num_frames(len(pcm))
+        compute = md.mfcc_compute(m, fixed=fixed)
+        parts = []
+        for rank in range(world):
+            shard, loc = md.process_frames_sharded(compute, pcm, rank, world, 13, n_frames=nf)
+            assert loc.shape == (shard.n_frames, 13)
+            parts.append(loc)
+        got = np.concatenate(parts)
+    assert got.shape == whole.shape and np.array_equal(got, whole)
+    if fixed:
+        assert np.array_equal(whole, mx.mfcc_fixed_ref(pcm, nceptrums=13, pad_mode=pad_mode))
+
+
+@pytest.mark.parametrize("nfft,nmel", [(64, 8), (128, 16), (256, 20)])
+def test_small_float_transforms_on_the_generic_kernel(mfcc_amd, nfft, nmel):
+    """`MFCC(nfft=...)` takes any power of two (mfcc.py:20, fft.py:351-353); the float contract for 64 and 128
+    runs on the generic kernel instead of failing at the first call."""
+    x = mf.synth_pcm(20000, seed=nfft)
+    hop = nfft // 3
+    for pad in ("notebook", "stream"):
+        with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=nmel, power_scale=0, pad_mode=pad) as m:
+            assert m.kernel_name().endswith("generic_kernel")
+            got = m.process(x)
+        ref = mf.mfcc_float_ref(x, n_cep=nmel, nfft=nfft, hop=hop, n_mel=nmel, power_scale=float(nfft), pad_mode=pad)
+        assert got.shape == ref.shape
+        e = np.abs(got - ref).max() / np.abs(ref).max()
+        assert e <= TOL, (nfft, pad, e)
+
+
+def test_device_path_refuses_a_bad_out_tensor(mfcc_amd):
+    import torch
+    x = torch.from_numpy(mf.synth_pcm(5000, seed=1)).cuda()
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13) as m:
+        nf = m.num_frames(5000)
+        good = torch.empty((1, nf, 13), device="cuda")
+        assert m.process(x[None], out=good) is good
+        ref = m.process(x)
+        assert torch.equal(good[0], ref)
+        for bad in (torch.empty((1, nf - 1, 13), device="cuda"), torch.empty((1, nf, 13), device="cuda", dtype=torch.float64),
+                    torch.empty((1, nf, 26), device="cuda")[:, :, ::2], torch.empty((1, nf, 13))):
+            with pytest.raises(ValueError):
+                m.process(x[None], out=bad)
+        with pytest.raises(ValueError):
+            m.process(x, halo=2)
+        # after a device-path call the handle is back on its own stream: a host-path call still works
+        assert np.array_equal(m.process(x.cpu().numpy()), ref.cpu().numpy())
