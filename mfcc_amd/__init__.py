@@ -5,7 +5,7 @@ Drop-in for the per-frame math of lambdaconcept/mfcc's ``mfcc/core`` and nothing
 mfcc_close / show_dir_content`` mirror the host driver (software/main.c).  All arithmetic runs
 in ``libmfcc_hip.so``; importing this package needs the library to be built (no CPU fallback).
 """
-from ._lib import MfccHipError, LIB_PATH, load as load_library  # noqa: F401
+from ._lib import MfccHipError, LIB_PATH, kernel_source_hash, load as load_library  # noqa: F401
 from . import wire  # noqa: F401  (serial wire format + power gate, software/serial.c, cepstrum.c)
 from .api import (MFCC, MfccStream, PAD_NOTEBOOK, PAD_STREAM, get_table, lift_file, lifter,  # noqa: F401
                   make_params, mfcc_close, mfcc_convert, mfcc_open, num_frames, show_dir_content)

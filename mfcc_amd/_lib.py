@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfcc_hip.so")
+# MFCC_HIP_LIB: diagnostic override for A/B runs of experimental builds of the same ABI (tools/ab.sh)
+LIB_PATH = os.environ.get("MFCC_HIP_LIB") or os.path.join(_HERE, "libmfcc_hip.so")
 
 ABI_VERSION = 2
 
@@ -144,6 +145,19 @@ def load():
                           (lib.mfcc_hip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources in csrc/: stamps the rocprofv3 summaries kept in
+    profiles/ so that bench.py can tell whether a committed counter figure still belongs to the kernels it runs."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hpp")) + glob.glob(os.path.join(src, "*.hip"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def check(code, what=""):

@@ -276,17 +276,51 @@ class MFCC:
         n = len(utts)
         offsets = np.zeros(n + 1, dtype=np.uint64)
         offsets[1:] = np.cumsum([u.numel() for u in utts], dtype=np.uint64)
-        flat = torch.cat(utts) if int(offsets[-1]) else torch.zeros(0, dtype=torch.int16, device=utts[0].device)
-        nf = sum(self.num_frames(u.numel()) for u in utts)
-        out = torch.empty((nf, self.nceptrums), device=utts[0].device, dtype=torch.int16 if fixed else torch.float32)
-        fo = np.zeros(n + 1, dtype=np.uint64)
+        # utterances that are consecutive views of one buffer (a corpus already laid out in HBM) are used in place
+        in_place = n > 0 and all(u.is_contiguous() for u in utts) and all(
+            utts[i].data_ptr() + 2 * utts[i].numel() == utts[i + 1].data_ptr() and
+            utts[i].untyped_storage().data_ptr() == utts[0].untyped_storage().data_ptr() for i in range(n - 1))
+        if in_place:
+            base = utts[0]
+            flat = torch.as_strided(base, (int(offsets[-1]),), (1,), storage_offset=base.storage_offset())
+        else:
+            flat = torch.cat(utts) if int(offsets[-1]) else torch.zeros(0, dtype=torch.int16, device=utts[0].device)
+        out, fo = self.process_packed(flat, offsets, fixed=fixed)
+        return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
+
+    def process_packed(self, flat, offsets, fixed=False, out=None):
+        """A corpus that already lies in HBM: ``flat`` = all utterances back to back (1-D CUDA int16 tensor),
+        utterance ``u`` = ``flat[offsets[u]:offsets[u + 1]]``.  ONE launch (``mfcc_hip_process_ragged_*_dev``),
+        asynchronous on the current stream.  Returns ``(out, frame_offsets)``: the dense ``(sum frames, nceptrums)``
+        result tensor and the row range of every utterance (``out[fo[u]:fo[u + 1]]``).  Equal-length utterances run
+        as channels of one multi-channel launch (no packing copy); the bits are the same."""
+        import torch
+        if flat.dtype != torch.int16 or not flat.is_cuda or flat.dim() != 1 or not flat.is_contiguous():
+            raise TypeError("flat must be a contiguous 1-D CUDA(HIP) int16 tensor")
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if n < 0 or (n >= 0 and len(offsets) and int(offsets[-1]) > flat.numel()):
+            raise ValueError("offsets run past the end of flat")
         self._check_device(flat)
+        lens = np.diff(offsets.astype(np.int64))
+        if (lens < 0).any():
+            raise ValueError("offsets must not decrease")
+        fo = np.zeros(n + 1, dtype=np.uint64)
+        uniq = np.unique(lens)
+        nf_of = {int(v): self.num_frames(int(v)) for v in uniq}
+        nf = int(sum(nf_of[int(v)] for v in lens)) if len(uniq) > 1 else (nf_of[int(uniq[0])] * n if n else 0)
+        odt = torch.int16 if fixed else torch.float32
+        if out is None:
+            out = torch.empty((nf, self.nceptrums), device=flat.device, dtype=odt)
+        elif tuple(out.shape) != (nf, self.nceptrums) or out.dtype != odt or not out.is_contiguous() or \
+                out.device != flat.device:
+            raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (odt, (nf, self.nceptrums), flat.device))
         fn = self._lib.mfcc_hip_process_ragged_fixed_i16_dev if fixed else self._lib.mfcc_hip_process_ragged_i16_dev
         with self._on_torch_stream(flat.device):
             _lib.check(fn(self._h, C.c_void_p(flat.data_ptr()), offsets.ctypes.data_as(C.c_void_p), n,
                           C.c_void_p(out.data_ptr()), out.numel(), fo.ctypes.data_as(C.c_void_p)), "process_ragged_dev")
         assert int(fo[-1]) == nf
-        return [out[int(fo[i]):int(fo[i + 1])] for i in range(n)]
+        return out, fo
 
     def time_launches(self, pcm, out, fixed=False, warmup=2, iters=10) -> float:
         """Average kernel time in ms over ``iters`` launches, HIP events on the launch stream."""

@@ -524,6 +524,16 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     }
     if (total == 0) return MFCC_HIP_SUCCESS;
     if (!d_out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
+    // A corpus of equal-length utterances lying back to back (BASELINE config 5: 10 000 x 10 s) IS a multi-channel
+    // stream, channel stride = utterance length: no packing copy, no row gather, the same bits (every channel of
+    // the plain call starts from reset, its frames are the utterance's frames and the rows come out dense).
+    {
+        const size_t n0 = offsets[1] - offsets[0];
+        bool uniform = n_utt >= 1 && count_frames(h->r, n0) > 0;
+        for (size_t u = 1; u < n_utt && uniform; ++u) uniform = offsets[u + 1] - offsets[u] == n0;
+        if (uniform)
+            return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
+    }
     const size_t F = pos / hop, len = pos + nfft + hop;
     const size_t desc_bytes = 6 * n_utt * sizeof(long long);
     rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);

@@ -25,7 +25,9 @@ import sys
 
 
 def main(src, dst):
-    out = {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mfcc_amd._lib import kernel_source_hash
+    out = {"kernel_source_hash": kernel_source_hash()}     # bench.py drops counter figures of other kernel sources
     ks = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)
     rows = []
     if ks:

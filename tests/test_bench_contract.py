@@ -45,6 +45,10 @@ def test_fixed_bench_line_reports_the_integer_path():
 
 def test_bench_only_uses_the_oracle_for_the_cpu_baseline():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert src.count("from oracle import") == 1
+    assert src.count("from oracle import") == 1 and src.count("import oracle") == 0
     i = src.index("from oracle import")
-    assert "no_cpu_baseline" in src[i - 400:i], "the oracle import must sit inside the cpu_baseline leg"
+    j = src.rindex("\ndef ", 0, i)
+    assert src[j:].startswith("\ndef cpu_baseline("), "the oracle import must sit inside the cpu_baseline leg"
+    # and that leg only runs when asked for, on rank 0, outside the timed regions
+    assert src.count("cpu_baseline(") == 3                       # the definition and its two guarded call sites
+    assert "if not args.no_cpu_baseline:" in src and "if with_cpu:" in src

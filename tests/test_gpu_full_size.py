@@ -60,33 +60,49 @@ def test_config4_full_size_64_channels_one_hour(mfcc_amd, wav_pcm):
         assert e_max <= TOL and e_l2 <= TOL, (c, e_max, e_l2)
 
 
-@pytest.mark.parametrize("fixed", [False, True])
-def test_config5_full_size_10k_utterances_one_launch(mfcc_amd, fixed):
+@pytest.fixture(scope="module")
+def corpus():
+    """config 5's corpus on the device: 10 000 utterances x 160 000 samples, seed = utterance id"""
     import torch
     n_utt, n = 10_000, 160_000
     g = torch.Generator(device="cuda")
     flat = torch.empty(n_utt * n, dtype=torch.int16, device="cuda")
-    for u in range(n_utt):                            # seed = utterance id
+    for u in range(n_utt):
         g.manual_seed(u)
         flat[u * n:(u + 1) * n] = (torch.randn(n, generator=g, device="cuda") * 3000.0).clamp_(-32768, 32767).to(torch.int16)
-    utts = [flat[u * n:(u + 1) * n] for u in range(n_utt)]
+    yield flat
+    del flat
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_config5_full_size_10k_utterances_one_launch(mfcc_amd, corpus, fixed, ragged):
+    """ragged=False: the corpus as defined (equal lengths: runs as 10 000 channels of one launch, no packing copy).
+    ragged=True: utterance u cut to 160 000 - 997 (u mod 5) samples -- the packed-stream path (pack kernel, one
+    launch over 9.3 M frames of ONE stream, row gather) at the same scale."""
+    import torch
+    n_utt, n = 10_000, 160_000
+    flat = corpus
+    lens = [n - 997 * (u % 5) if ragged else n for u in range(n_utt)]
+    utts = [flat[u * n:u * n + lens[u]] for u in range(n_utt)]
     pad = "stream" if fixed else "notebook"
     with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode=pad) as m:
-        per = m.num_frames(n)
-        assert per == (940 if fixed else 939)
+        per = [m.num_frames(v) for v in sorted(set(lens), reverse=True)]
+        assert per[0] == (940 if fixed else 939)
         got = m.process_batch(utts, fixed=fixed)
         torch.cuda.synchronize()
-        assert len(got) == n_utt and sum(len(r) for r in got) == n_utt * per
-        base = got[0].data_ptr()
+        total = sum(m.num_frames(v) for v in lens)
+        assert len(got) == n_utt and sum(len(r) for r in got) == total and total > 9_200_000
         esz = 2 if fixed else 4
-        assert got[-1].data_ptr() == base + (n_utt - 1) * per * 13 * esz          # one dense result buffer
-        if not fixed:
-            dense = torch.as_strided(got[0], (n_utt, per, 13), (per * 13, 13, 1))
-            assert bool(torch.isfinite(dense).all())
-        # uniform lengths: the plain multi-channel call must give the same bits as the ragged launch
-        multi = (m.process_fixed if fixed else m.process)(flat.view(n_utt, n)[:2000])
-        for u in (0, 1, 999, 1999):
-            assert torch.equal(multi[u], got[u]), u
+        assert got[-1].data_ptr() == got[0].data_ptr() + (total - len(got[-1])) * 13 * esz    # one dense result buffer
+        dense = torch.as_strided(got[0], (total, 13), (13, 1))
+        assert bool(torch.isfinite(dense.float()).all())
+        if not ragged:
+            # equal lengths: the plain multi-channel call gives the same bits
+            multi = (m.process_fixed if fixed else m.process)(flat.view(n_utt, n)[:2000])
+            for u in (0, 1, 999, 1999):
+                assert torch.equal(multi[u], got[u]), u
         # a sample of utterances: per-utterance calls (bit for bit) and the oracle
         for u in (0, 1, 2, 4999, 5000, 7777, 9998, 9999):
             x = utts[u].cpu().numpy()
