@@ -1,5 +1,5 @@
 // Fused 1024/341/40 float kernel for gfx950 (MI355X) -- BASELINE.json configs[3]: nfft 1024, hop
-// 1024//3 = 341 (mfcc/core/mfcc.py:43), 40 mel bands, n_cep <= 16, the mel contraction on the matrix
+// 1024//3 = 341 (mfcc/core/mfcc.py:43), 40 mel bands, n_cep <= 32, the mel contraction on the matrix
 // cores.  Same scheme as kernel_fused512.hpp (read its header first); what differs:
 //
 //  * a workgroup of EIGHT waves owns a tile of 16 consecutive frames, one workgroup per CU (118 KB of
@@ -33,7 +33,7 @@
 
 namespace mfcc_fused1024 {
 
-constexpr int kNfft = 1024, kHop = 341, kMel = 40, kMaxCep = 16;
+constexpr int kNfft = 1024, kHop = 341, kMel = 40, kMaxCep = 32;   // 32: what the reference tops keep (main.c:13)
 constexpr int kTile = 16, kWaves = 8;
 constexpr int kTileHop = kTile * kHop;            // 5456 samples between consecutive tiles
 constexpr int kTRow = 34;                         // words per n2 row of the transpose tile (16 complex + 2)
@@ -75,7 +75,9 @@ struct Tables {
     const float *win;      // [32 n2][32 n1]  hamming[32 n1 + n2] / 64
     const float *tw;       // [32 n2][16 k1][2] W1024^(n2 k1)
     const float *a_mel;    // [8 waves][18][64]
-    const float *a_extra;  // [3 roles][12][64]  role 0: DCT rows; role 1 / 2: column-16 DFT (8) + its mel weights
+    const float *a_extra;  // [3 roles][12][64]  role 0: DCT rows; role 1 / 2: column-16 DFT (8) + its mel weights;
+                           // then [12][64]: DCT rows of coefficients 16..31 (fetched per tile, only when n_cep > 16: the
+                           // kernel has no registers left to keep them)
     int n_cep;
 };
 
@@ -94,7 +96,7 @@ inline int bin_of(int k1, int h, int m) {
 inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep, std::vector<char> &blob) {
     using namespace mfcc_tables;
     std::vector<float> win(32 * 32), tw(32 * 16 * 2), amel(size_t(kWaves) * kAmel * 64, 0.0f),
-        aext(size_t(3) * kAextra * 64, 0.0f);
+        aext(size_t(4) * kAextra * 64, 0.0f);
     std::vector<double> w = hamming_periodic(kNfft);
     for (int n2 = 0; n2 < 32; ++n2)
         for (int n1 = 0; n1 < 32; ++n1) win[n2 * 32 + n1] = float(w[32 * n1 + n2] / 64.0);
@@ -132,6 +134,7 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
             for (int l = 0; l < 64; ++l) {
                 const int coeff = l & 15, filt = 16 * blk + 4 * (l >> 4) + r;
                 E(0, 4 * blk + r, l) = (coeff < n_cep && filt < kMel) ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
+                E(3, 4 * blk + r, l) = (16 + coeff < n_cep && filt < kMel) ? float(dd[size_t(16 + coeff) * kMel + filt]) : 0.0f;
             }
     // roles 1, 2 -- column 16: X[16 + 32 j] = sum_n2 v[n2] W1024^(n2 (16 + 32 j)); MFMA row i = 4 g + r holds
     // r = 0: Re j = jb + 2 g, r = 1: Im (same j), r = 2: Re j + 1, r = 3: Im; K step t covers n2 = 4 t + (l >> 4)
@@ -236,17 +239,34 @@ __device__ __forceinline__ void mel_log2(const float *Qt, int lane, int q, f32x4
     if (q >= 2) lm[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// d[0] + d[1] + d[2] = the DCT of the previous tile (its 12 MFMAs are issued by the caller)
+// d[0] + d[1] + d[2] = the DCT of the previous tile (its 12 MFMAs are issued by the caller); coefficients 16..31 are a
+// second M tile whose A operands are fetched here (uniform branch; 12 coalesced dwords per lane out of L1 / L2)
 __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tables &t, const f32x4 (&d)[kBlocks],
-                                          const Cursor &c, int lo, int q, int lane_off, float *__restrict__ out) {
+                                          const f32x4 (&lm)[kBlocks], const Cursor &c, int lo, int q, int lane,
+                                          int lane_off, float *__restrict__ out) {
     const f32x4 d0 = d[0], d1 = d[1], d2 = d[2];
     const long long fr0 = (long long)c.t_in * kTile;
     const long long rows_left = s.frames_per_ch - fr0;
+    float *o = out + ((long long)c.ch * s.frames_per_ch + fr0) * t.n_cep + lane_off;
     if (lo < rows_left) {
-        float *o = out + ((long long)c.ch * s.frames_per_ch + fr0) * t.n_cep + lane_off;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (4 * q + r < t.n_cep) o[r] = (d0[r] + d1[r]) + d2[r];
+    }
+    if (t.n_cep > 16) {
+        const float *hi = t.a_extra + (size_t)3 * kAextra * 64 + lane;
+        asm volatile("" : "+v"(hi));                   // not hoisted out of the tile loop: no registers to hold it
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 e[kBlocks] = {zero, zero, zero};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) e[b] = MFCC1K_MFMA(hi[(4 * b + r) * 64], lm[b][r], e[b]);
+        if (lo < rows_left) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 + 4 * q + r < t.n_cep) o[16 + r] = (e[0][r] + e[1][r]) + e[2][r];
+        }
     }
 }
 
@@ -397,7 +417,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
         if (role == 0) {
             f32x4 d[kBlocks] = {zero, zero, zero};
             mel_dct_mfmas(pw, am, ax, lm, acc, d);           // lm = 0 before the first tile
-            if (have_prev) dct_store(s, t, d, prev, lo, q, lane_off, out);
+            if (have_prev) dct_store(s, t, d, lm, prev, lo, q, lane, lane_off, out);
         } else if (h) {
             mel_mfmas<1>(pw, am, acc);
         } else {
@@ -419,7 +439,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int b = 0; b < kBlocks; ++b) d[b] = MFCC1K_MFMA(ax[4 * b + r], lm[b][r], d[b]);
-        dct_store(s, t, d, prev, lo, q, lane_off, out);
+        dct_store(s, t, d, lm, prev, lo, q, lane, lane_off, out);
     }
 }
 

@@ -20,20 +20,22 @@
 //  pass 2  wave w, lane (j = lane&15, g = lane>>4) reads column k1 = 4 w + g of frame j from T and
 //          runs a complex 16-point FFT over n2: X[k1 + 32 k2], k2 = 0..15.  The input being real,
 //          each of these is a distinct needed bin (k or 512-k): no real-FFT split step.
-//  MFMA    |X|^2 is now in registers in exactly the B-operand layout of the MFMA (column = frame j,
-//          K index = g): the mel contraction W (32 x 257, block-banded) . P runs as 17 MFMAs per wave
-//          straight from registers (A = this wave's weights, resident for the whole kernel) -- the
-//          power spectrum never touches LDS.  Each wave ends with partial sums over its 64 bins;
-//          they meet in the LDS tile Q.  One wave ("role 1") also turns column 16 into bins 16+32j
-//          with a 16x16 real DFT matrix (4 MFMAs) and feeds them (4 MFMAs).  Another ("role 0")
-//          finishes the PREVIOUS tile in this window: log2 of the summed mel energies, DCT-II as 8
-//          MFMAs (16 for n_cep > 16) whose B operand IS the mel accumulator layout (K index permuted,
-//          no lane movement), interleaved with its mel MFMAs; store n_cep floats per frame.  Nobody
-//          waits for that tail.
+//  MFMA    |X|^2 is now in registers in exactly the B-operand layout of the matrix instructions (column = frame j,
+//          K index = g): the mel contraction W (32 x 257, block-banded) . P runs straight from registers (A = this
+//          wave's weights, resident for the whole kernel) -- the power spectrum never touches LDS.  It runs on
+//          v_mfma_f32_16x16x32_bf16 with both operands split in two bf16 terms (W = Wh + Wl, P = Ph + Pl; Wh Ph +
+//          Wh Pl + Wl Ph, fp32 accumulation: 2^-17 relative, far inside the fp32 noise of the FFT): 9 MFMAs of 16
+//          clocks per wave and tile instead of 17 fp32 ones of 32 -- on gfx950 an fp32 MFMA holds the SIMD's vector
+//          pipe for its whole duration (tools/alu_probe.hip), a bf16 one does not.  Each wave ends with partial sums
+//          over its 64 bins; they meet in the LDS tile Q.  One wave ("role 1") also turns column 16 into bins
+//          16+32j with a 16x16 real DFT matrix (4 fp32 MFMAs) and feeds them (4).  Another ("role 0") finishes the
+//          PREVIOUS tile in this window: log2 of the summed mel energies, DCT-II as 8 fp32 MFMAs (16 for n_cep > 16)
+//          whose B operand IS the mel accumulator layout (K index permuted, no lane movement), interleaved with its
+//          mel MFMAs; store n_cep floats per frame.  Nobody waits for that tail.
 //  ---- workgroup barrier B2 ----
 //
-// Two instantiations: the BANDED MFMA list above is the mel matrix at 16 kHz; DENSE issues all 32
-// (k2, block) pairs and serves every other sample rate and the 16-filter bank (struct Sched).
+// Instantiations: the BANDED set list (struct SetsBf) is the mel matrix at 16 kHz; DENSE issues every (filter block,
+// K group) pair and serves every other sample rate and the 16-filter bank; DCX adds the double-precision DC bin.
 //
 // HBM traffic per frame: 170 new int16 samples + 13 floats out = 392 B (plus the 342-sample overlap
 // between consecutive tiles, 11 %).  The kernel is bound by the CU's VALU and LDS pipes (86 VALU
@@ -45,6 +47,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "codelets_gen.hpp"
@@ -66,6 +69,31 @@ constexpr int kTFrame = 16 * kTRow + 2;   // 546 words per frame (== 2 mod 32): 
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
 constexpr int kAmelBanded = 17;           // mel A operands per wave at 16 kHz: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
 constexpr int kAmelDense = 32;            // any other band structure: every (k2, block) pair
+// MFCC_MEL_BF16: the mel contraction on v_mfma_f32_16x16x32_bf16 with both operands split in two bf16 terms
+// (W = Wh + Wl, P = Ph + Pl, products Wh Ph + Wh Pl + Wl Ph: 2^-17 relative, fp32 accumulation).  On gfx950 the fp32
+// MFMA is vector-pipe time (tools/alu_probe.hip: an MFMA and k VALU ops of ONE wave take 32 + 4.5 k clocks, and a wave
+// issuing them back to back holds its SIMD partner to one VALU op per MFMA), so 17 of them per wave and tile were 40 %
+// of the kernel's pipe clocks; a K = 32 bf16 MFMA takes 16 clocks on the matrix pipe and covers eight times the bins.
+#ifndef MFCC_MEL_BF16
+#define MFCC_MEL_BF16 1
+#endif
+// K slots of the two bf16 MFMAs of a lane: K index 8 g + j  <->  bin(w, g, k2 = kGrp[grp][j])
+constexpr int kGrpK2[2][8] = {{0, 1, 14, 15, 2, 3, 12, 13}, {4, 5, 6, 7, 8, 9, 10, 11}};
+// (filter block, K group) sets of a wave.  BANDED (16 kHz): block 0 only touches k2 in {0, 1, 14, 15} -- group 0
+template <bool DENSE>
+struct SetsBf;
+template <>
+struct SetsBf<false> {
+    static constexpr int N = 3;
+    static constexpr int blk[N] = {0, 1, 1};
+    static constexpr int grp[N] = {0, 0, 1};
+};
+template <>
+struct SetsBf<true> {
+    static constexpr int N = 4;
+    static constexpr int blk[N] = {0, 0, 1, 1};
+    static constexpr int grp[N] = {0, 1, 0, 1};
+};
 constexpr int kAextra = 16;               // role operands: role 0 DCT (8 + 8 for coefficients 16..31); role 1
                                           // column-16 DFT (4) + its mel (4)
 constexpr int kFetchers = 192;            // threads that fetch and park the sample window: roles 1..3
@@ -95,6 +123,7 @@ struct FusedTables {
     const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 64 (pre-emphasis x32, real-FFT split x2)
     const float2 *tw;     // [16 n2][16 k1]   W512^(n2 k1)
     const float *a_mel;   // [4 waves][17][64] mel weights of the bins wave w transforms, in consumption order
+    const uint32_t *a_mel_bf; // [4 waves][sets][hi, lo][4 dwords][64] the same weights as bf16 pairs (MFCC_MEL_BF16)
     const float *a_extra; // [4 roles][8][64]  role 0: DCT rows; role 1: column-16 DFT + its mel weights
     const double *win_dc; // [16 n2][32 n1]   hamming[16 n1 + n2] / 32 in double -- or nullptr.  Set when a mel filter has
                           // weight on bin 0 (any sample rate whose first two filter points are both 0: 44.1 kHz, 48 kHz ...).
@@ -219,8 +248,53 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         blob.resize(off + v.size() * 4);
         std::memcpy(blob.data() + off, v.data(), v.size() * 4);
     };
+    // bf16 split of the same weights for the K = 32 MFMAs: lane l of wave wv, set s, holds rows m = l & 15 of filter
+    // block blk[s] at K slots j = 0..7 <-> bin(wv, l >> 4, kGrpK2[grp[s]][j]); dword d = slots (2 d, 2 d + 1)
+    constexpr int kSets = SetsBf<DENSE>::N;
+    std::vector<float> abf(size_t(kWaves) * kSets * 2 * 4 * 64, 0.0f);      // uint32 payload, moved as floats
+    {
+        auto bf16_round = [](float v) -> uint32_t {                          // round to nearest even, like v_cvt_pk_bf16_f32
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return u >> 16;
+        };
+        auto bf16_val = [](uint32_t h) -> float {
+            uint32_t u = h << 16;
+            float v;
+            std::memcpy(&v, &u, 4);
+            return v;
+        };
+        std::vector<char> cov2(size_t(kMel) * 257, 0);
+        for (int wv = 0; wv < kWaves; ++wv)
+            for (int st = 0; st < kSets; ++st)
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t hi[8], lo[8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int k2 = kGrpK2[SetsBf<DENSE>::grp[st]][j];
+                        const int filt = SetsBf<DENSE>::blk[st] * 16 + (l & 15), k1 = 4 * wv + (l >> 4);
+                        float wgt = 0.0f;
+                        if (!(k1 == 0 && k2 > 8)) {
+                            const int bin = k2 < 8 ? k1 + 32 * k2 : 32 * (16 - k2) - k1;
+                            wgt = float(md[size_t(filt) * 257 + bin] * inv);
+                            cov2[size_t(filt) * 257 + bin] = 1;
+                        }
+                        hi[j] = bf16_round(wgt);
+                        lo[j] = bf16_round(wgt - bf16_val(hi[j]));
+                    }
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t vh = hi[2 * d] | (hi[2 * d + 1] << 16), vl = lo[2 * d] | (lo[2 * d + 1] << 16);
+                        std::memcpy(&abf[((size_t(wv) * kSets + st) * 2 + 0) * 256 + d * 64 + l], &vh, 4);
+                        std::memcpy(&abf[((size_t(wv) * kSets + st) * 2 + 1) * 256 + d * 64 + l], &vl, 4);
+                    }
+                }
+        // the sets must cover what the fp32 schedule covers (bins 16 mod 32 come from column 16 either way)
+        for (int f = 0; f < kMel; ++f)
+            for (int k = 0; k < 257; ++k)
+                if (md[size_t(f) * 257 + k] != 0.0 && !cov2[size_t(f) * 257 + k] && (k & 31) != 16) return false;
+    }
     blob.clear();
-    put(win); put(tw); put(amel); put(aext);
+    put(win); put(tw); put(amel); put(aext); put(abf);
     // double-precision window rows for the DC bin (8-byte aligned: everything before is a multiple of 8 bytes)
     std::vector<double> wd(16 * 32);
     for (int n2 = 0; n2 < 16; ++n2)
@@ -241,6 +315,8 @@ inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, bool dc
     t.tw = reinterpret_cast<const float2 *>(f); f += 16 * 16 * 2;
     t.a_mel = f;                f += kWaves * kAmel * 64;
     t.a_extra = f;              f += kWaves * kAextra * 64;
+    t.a_mel_bf = reinterpret_cast<const uint32_t *>(f);
+    f += kWaves * (dense ? SetsBf<true>::N : SetsBf<false>::N) * 2 * 4 * 64;
     t.win_dc = dc_exact ? reinterpret_cast<const double *>(f) : nullptr;
 }
 
@@ -361,6 +437,68 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Fus
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFCC_MFMA_BF(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// (a, b) -> their bf16 roundings packed in one dword (a low) and the bf16 roundings of what the first rounding lost
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t &hi, uint32_t &lo) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
+}
+
+// |X|^2 of a lane's 16 bins -> the B operands of the two K groups, high and low terms
+struct PowerBf {
+    u32x4 hi[2], lo[2];
+};
+__device__ __forceinline__ void split_power(const float (&pw)[16], PowerBf &p) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t h, l;
+            split_bf16_pair(pw[kGrpK2[g][2 * d]], pw[kGrpK2[g][2 * d + 1]], h, l);
+            p.hi[g][d] = h;
+            p.lo[g][d] = l;
+        }
+}
+
+// term T (0: Wh Ph, 1: Wh Pl, 2: Wl Ph) of set S; one accumulator per set (chains of three, interleaved by the caller)
+template <bool DENSE, int S, int T>
+__device__ __forceinline__ void mel_bf_term(const u32x4 (&ah)[SetsBf<DENSE>::N], const u32x4 (&al)[SetsBf<DENSE>::N],
+                                            const PowerBf &p, f32x4 (&acc)[SetsBf<DENSE>::N]) {
+    constexpr int g = SetsBf<DENSE>::grp[S];
+    if constexpr (T == 0) acc[S] = MFCC_MFMA_BF(ah[S], p.hi[g], acc[S]);
+    if constexpr (T == 1) acc[S] = MFCC_MFMA_BF(ah[S], p.lo[g], acc[S]);
+    if constexpr (T == 2) acc[S] = MFCC_MFMA_BF(al[S], p.hi[g], acc[S]);
+}
+
+// all terms of all sets, term-major (consecutive MFMAs never share an accumulator); AFTER(i) runs after MFMA number i
+template <bool DENSE, int I, typename After>
+__device__ __forceinline__ void mel_bf_all(const u32x4 (&ah)[SetsBf<DENSE>::N], const u32x4 (&al)[SetsBf<DENSE>::N],
+                                           const PowerBf &p, f32x4 (&acc)[SetsBf<DENSE>::N], After &&after) {
+    constexpr int N = SetsBf<DENSE>::N;
+    if constexpr (I < 3 * N) {
+        mel_bf_term<DENSE, I % N, I / N>(ah, al, p, acc);
+        after(std::integral_constant<int, I>{});
+        mel_bf_all<DENSE, I + 1>(ah, al, p, acc, after);
+    }
+}
+
+// sums of the set accumulators per filter block
+template <bool DENSE>
+__device__ __forceinline__ void mel_bf_blocks(const f32x4 (&acc)[SetsBf<DENSE>::N], f32x4 &b0, f32x4 &b1) {
+    if constexpr (DENSE) {
+        b0 = acc[0] + acc[1];
+        b1 = acc[2] + acc[3];
+    } else {
+        b0 = acc[0];
+        b1 = acc[1] + acc[2];
+    }
+}
+
 // one mel MFMA of the schedule: block 0 accumulates in (x0, y0), block 1 in (x1, y1), alternating
 template <bool DENSE, int I>
 __device__ __forceinline__ void mel_step(const float (&am)[Sched<DENSE>::N], const float (&pw)[16], f32x4 &x0, f32x4 &y0,
@@ -398,7 +536,7 @@ __device__ __forceinline__ void mel_dct_steps(const float (&am)[Sched<DENSE>::N]
 template <bool DENSE, bool DCX>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
-    constexpr int kAmel = Sched<DENSE>::N;
+    [[maybe_unused]] constexpr int kAmel = Sched<DENSE>::N;
     __shared__ __attribute__((aligned(16))) float lds[kLdsWords + (DCX ? kDcxWords : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -428,15 +566,29 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     v2f tw[16];                                    // W512^(n2 k1) as (cos, sin)
 #pragma unroll
     for (int i = 0; i < 16; ++i) tw[i] = reinterpret_cast<const v2f *>(t.tw)[lo * 16 + i];
-    float am[kAmel], ax[kAextra];
+    float ax[kAextra];
+#if MFCC_MEL_BF16
+    constexpr int kSets = SetsBf<DENSE>::N;
+    u32x4 ah[kSets], al[kSets];
+#pragma unroll
+    for (int st = 0; st < kSets; ++st)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            ah[st][d] = t.a_mel_bf[((wave * kSets + st) * 2 + 0) * 256 + d * 64 + lane];
+            al[st][d] = t.a_mel_bf[((wave * kSets + st) * 2 + 1) * 256 + d * 64 + lane];
+        }
+#else
+    float am[kAmel];
 #pragma unroll
     for (int i = 0; i < kAmel; ++i) am[i] = t.a_mel[(wave * kAmel + i) * 64 + lane];
+#endif
 #pragma unroll
     for (int i = 0; i < kAextra; ++i) ax[i] = t.a_extra[(role * kAextra + i) * 64 + lane];
 
     // slot of this lane's sample n1 = 0 in the window, before the per-tile alignment shift
     const int lane_slot = fr_id * kHop + lo;
     const int fetcher = (role - 1) * 64 + lane;     // 0..191 in roles 1..3
+    const bool fetches = role != 0;
     const int lane_off = lo * t.n_cep + 4 * q;
 
     Cursor cur;
@@ -450,7 +602,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
     if (cur.ch < g.n_ch) {
         const Window w0 = window_of(cur, g);
         shift = w0.shift;
-        if (role != 0) {
+        if (fetches) {
             fetch_window(s, w0, fetcher, fx);
             park_window(Sf, fetcher, fx);
         }
@@ -500,7 +652,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         if (more) {
             const Window wn = window_of(cur, g);
             next_shift = wn.shift;
-            if (role != 0) fetch_window(s, wn, fetcher, fx);
+            if (fetches) fetch_window(s, wn, fetcher, fx);
         }
         if (role == 0 && have_prev) mel_log2(Qt, lane, t.n_mel, lm0, lm1);
         MFCC_STAMP(6);
@@ -550,6 +702,54 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
 
         // ---------------- MFMA window (frame column = lo, K index = q)
         f32x4 x0 = zero, y0 = zero, x1 = zero, y1 = zero;
+#if MFCC_MEL_BF16
+        PowerBf pb;
+        split_power(pw, pb);
+        f32x4 acc[kSets];
+#pragma unroll
+        for (int st = 0; st < kSets; ++st) acc[st] = zero;
+        if (role == 0) {
+            // this tile's mel MFMAs with the previous tile's DCT MFMAs (coefficients 0..15, fp32) in between
+            f32x4 d0 = zero, d1 = zero;
+            mel_bf_all<DENSE, 0>(ah, al, pb, acc, [&](auto i) {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < 8) {
+                    constexpr int r = I >> 1;
+                    if constexpr (I & 1) d1 = MFCC_MFMA(ax[4 + r], lm1[r], d1);
+                    else d0 = MFCC_MFMA(ax[r], lm0[r], d0);
+                }
+            });
+            mel_bf_blocks<DENSE>(acc, x0, x1);
+            MFCC_STAMP(8);
+            if (have_prev) dct_store(s, t, lm0, lm1, d0, d1, ax, prev, lo, q, lane_off, out);
+        } else if (role == 1) {
+            // column 16 -> bins 16 + 32 j of this tile (a 16 x 16 real DFT matrix on fp32 MFMAs), fed to both filter
+            // blocks from registers at the end
+            const float v0 = Vt[lo * kVStride + 0 + q], v1 = Vt[lo * kVStride + 4 + q];
+            const float v2 = Vt[lo * kVStride + 8 + q], v3 = Vt[lo * kVStride + 12 + q];
+            f32x4 sp = zero, sp2 = zero;
+            mel_bf_all<DENSE, 0>(ah, al, pb, acc, [&](auto i) {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I == 0) sp = MFCC_MFMA(ax[0], v0, sp);
+                if constexpr (I == 1) sp2 = MFCC_MFMA(ax[1], v1, sp2);
+                if constexpr (I == 2) sp = MFCC_MFMA(ax[2], v2, sp);
+                if constexpr (I == 3) sp2 = MFCC_MFMA(ax[3], v3, sp2);
+            });
+            mel_bf_blocks<DENSE>(acc, x0, x1);
+            sp += sp2;
+            const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
+            const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
+            x0 = MFCC_MFMA(ax[4], s0, x0);
+            y0 = MFCC_MFMA(ax[5], s1, y0);
+            x1 = MFCC_MFMA(ax[6], s0, x1);
+            y1 = MFCC_MFMA(ax[7], s1, y1);
+            MFCC_STAMP(8);
+        } else {
+            mel_bf_all<DENSE, 0>(ah, al, pb, acc, [](auto) {});
+            mel_bf_blocks<DENSE>(acc, x0, x1);
+            MFCC_STAMP(8);
+        }
+#else
         if (role == 0) {
             // this tile's mel MFMAs and the previous tile's DCT MFMAs (coefficients 0..15) in ONE basic block,
             // interleaved: six independent accumulator chains instead of two long tails (lm = 0 before the
@@ -581,6 +781,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
             mel_steps<DENSE, 0, kAmel>(am, pw, x0, y0, x1, y1);
             MFCC_STAMP(8);
         }
+#endif
         MFCC_STAMP(9);
         *reinterpret_cast<f32x4 *>(Qt + (2 * wave + 0) * 256 + lane * 4) = x0 + y0;
         *reinterpret_cast<f32x4 *>(Qt + (2 * wave + 1) * 256 + lane * 4) = x1 + y1;
@@ -588,7 +789,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         have_prev = true;
         MFCC_STAMP(10);
         // park the next tile's sample window (every read of the current one happened before B1)
-        if (more && role != 0) park_window(Sf, fetcher, fx);
+        if (more && fetches) park_window(Sf, fetcher, fx);
         shift = next_shift;
         MFCC_STAMP(4);
         lds_barrier();                         // B2: partial sums and S are in LDS, T/V may be overwritten

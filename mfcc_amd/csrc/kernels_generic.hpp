@@ -50,6 +50,7 @@ struct FloatTables {
     const int    *mel_count;  // [n_mel]
     const int    *mel_off;    // [n_mel] offset into mel_w
     const float  *mel_w;      // packed weights, 1/power_scale^2 folded in
+    int mel_w_total;          // entries of mel_w: at most 2 per bin (staged in LDS by the kernel)
     const float  *dct;        // [n_cep][n_mel] (lifter folded in)
     const double *window_d;   // [NFFT] the window in double, or nullptr: set when a mel filter has weight on bin 0 --
                               // that bin is then accumulated in double (kernel_fused512.hpp, FusedTables::win_dc)
@@ -76,6 +77,9 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
     __shared__ float2 bufA[kWavesPerBlock][M];
     __shared__ float2 bufB[kWavesPerBlock][M + 1];
     __shared__ float  melv[kWavesPerBlock][kMaxMel];
+    __shared__ float  melw[NFFT + 8];           // the filterbank weights, once per workgroup: a filter's tap loop would
+    for (int i = threadIdx.x; i < t.mel_w_total; i += kBlock) melw[i] = t.mel_w[i];   // otherwise wait for a global load per tap
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -171,8 +175,9 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
         // mel filterbank (cells 30, 36) + log2
         if (lane < t.n_mel) {
             const int st = t.mel_start[lane], cnt = t.mel_count[lane];
-            const float *w = t.mel_w + t.mel_off[lane];
+            const float *w = melw + t.mel_off[lane];
             float acc = 0.0f;
+#pragma unroll 4
             for (int j = 0; j < cnt; ++j) acc = fmaf(P[st + j], w[j], acc);
             melv[wave][lane] = log2f(acc);
         }
@@ -199,8 +204,9 @@ struct FixedTables {
     const int   *mel_count;   // [n_mel]
     const int   *mel_off;     // [n_mel]
     const uint32_t *mel_w;    // packed weights (x 2^-30)
+    int mel_w_total;          // entries of mel_w (staged in LDS by the kernel)
     int mel_shift;
-    int nfft, log2_nfft, n_mel, log2_dct, n_cep;
+    int nfft, log2_nfft, n_mel, log2_mel, log2_dct, n_cep;
 };
 
 __device__ __forceinline__ int wrap16(int v) { return (int)(short)(v & 0xFFFF); }
@@ -246,51 +252,136 @@ __device__ __forceinline__ void fx_bfly(uint32_t &p0, uint32_t &p1, uint32_t twa
     fx_combine(p0, fx_rot14(p1, twa), fx_rot14(p1, twb), p0, p1);
 }
 
-// in-place radix-2 DIT over `size` packed points held in LDS (bit-reversed input order); schedule of
-// mfcc/misc/fft.py:216-344 (see oracle/mfcc_fixed.py: fft_fixed); tw: packed operand pairs [size/2]
-__device__ __forceinline__ void fx_fft_inplace(uint32_t *x, int size, int L, const uint2 *tw, int lane) {
+// LDS index of point i of the in-place FFT buffer: one pad word per 32 points.  The butterfly groups of a stage
+// sit 2^st points apart, so without the pad the lanes of a wave hit 4..8 distinct banks (measured on the plain
+// layout: SQ_LDS_BANK_CONFLICT = 69 % of SQ_LDS_IDX_ACTIVE)
+__device__ __forceinline__ int fxi(int i) { return i + (i >> 5); }
+
+// S consecutive radix-2 DIT stages st .. st + S - 1 on 2^S register-resident points per lane group, ONE LDS round
+// trip: group gidx holds the points base + a 2^st, a = 0 .. 2^S - 1, with j = gidx mod 2^st and
+// base = (gidx >> st) << (st + S) | j.  Stage st + u pairs a with a | 2^u; the element's index inside that stage's
+// butterfly group is j + (a mod 2^u) 2^st.  Every butterfly is the RTL's own (fx_bfly) on the same operands as in the
+// stage-by-stage schedule of mfcc/misc/fft.py:216-344, so the result is the same bit for bit.
+template <int S>
+__device__ __forceinline__ void fx_fft_pass(uint32_t *x, int size, int L, int st, const uint2 *tw, int lane) {
     const int half = size >> 1;
-    for (int st = 0; st < L; ++st) {
-        for (int tp = lane; tp < half; tp += 64) {
-            const int j = tp & ((1 << st) - 1);
-            const int i0 = ((tp >> st) << (st + 1)) | j;
-            const int i1 = i0 + (1 << st);
-            const int ta = (j << (L - 1 - st)) & (half - 1);
-            uint32_t p0 = x[i0], p1 = x[i1];
-            const uint2 w = tw[ta];
-            fx_bfly(p0, p1, w.x, w.y);
-            x[i0] = p0;
-            x[i1] = p1;
+    for (int gidx = lane; gidx < (size >> S); gidx += 64) {
+        const int j = gidx & ((1 << st) - 1);
+        const int base = ((gidx >> st) << (st + S)) | j;
+        uint32_t v[1 << S];
+#pragma unroll
+        for (int a = 0; a < (1 << S); ++a) v[a] = x[fxi(base + (a << st))];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+#pragma unroll
+            for (int a = 0; a < (1 << S); ++a) {
+                if (a & (1 << u)) continue;
+                const int jj = j + ((a & ((1 << u) - 1)) << st);
+                const uint2 w = tw[(jj << (L - 1 - (st + u))) & (half - 1)];
+                fx_bfly(v[a], v[a | (1 << u)], w.x, w.y);
+            }
         }
-        wave_sync();
+#pragma unroll
+        for (int a = 0; a < (1 << S); ++a) x[fxi(base + (a << st))] = v[a];
     }
+    wave_sync();
+}
+
+// the same with every size known at compile time (the frame FFT): index arithmetic folds to a few shifts, loops unroll
+template <int S, int L, int ST>
+__device__ __forceinline__ void fx_fft_pass_ct(uint32_t *x, const uint2 *tw, int lane) {
+    constexpr int size = 1 << L, half = size >> 1, groups = size >> S;
+#pragma unroll 1
+    for (int g0 = 0; g0 < groups; g0 += 64) {
+        const int gidx = g0 + lane;
+        if (groups >= 64 || gidx < groups) {
+            const int j = gidx & ((1 << ST) - 1);
+            const int base = ((gidx >> ST) << (ST + S)) | j;
+            uint32_t v[1 << S];
+#pragma unroll
+            for (int a = 0; a < (1 << S); ++a) v[a] = x[fxi(base + (a << ST))];
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+#pragma unroll
+                for (int a = 0; a < (1 << S); ++a) {
+                    if (a & (1 << u)) continue;
+                    const int jj = j + ((a & ((1 << u) - 1)) << ST);
+                    const uint2 w = tw[(jj << (L - 1 - (ST + u))) & (half - 1)];
+                    fx_bfly(v[a], v[a | (1 << u)], w.x, w.y);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < (1 << S); ++a) x[fxi(base + (a << ST))] = v[a];
+        }
+    }
+    wave_sync();
+}
+
+// stages ST .. L - 1 in passes of S stages where that keeps all 64 lanes busy (2^L >> S >= 64), fewer otherwise
+template <int L, int ST>
+__device__ __forceinline__ void fx_fft_ct(uint32_t *x, const uint2 *tw, int lane) {
+    if constexpr (ST < L) {
+        constexpr int left = L - ST;
+        constexpr int want = (L >= 9) ? 3 : (L >= 8 ? 2 : 1);
+        constexpr int S = left < want ? left : want;
+        fx_fft_pass_ct<S, L, ST>(x, tw, lane);
+        fx_fft_ct<L, ST + S>(x, tw, lane);
+    }
+}
+
+// in-place radix-2 DIT over `size` packed points held in LDS (bit-reversed input order), three stages per LDS round
+// trip (then what is left); schedule of mfcc/misc/fft.py:216-344 (see oracle/mfcc_fixed.py: fft_fixed); tw: packed
+// operand pairs [size/2]
+__device__ __forceinline__ void fx_fft_inplace(uint32_t *x, int size, int L, const uint2 *tw, int lane) {
+    int st = 0;
+    for (; st + 3 <= L; st += 3) fx_fft_pass<3>(x, size, L, st, tw, lane);
+    if (L - st == 2) fx_fft_pass<2>(x, size, L, st, tw, lane);
+    else if (L - st == 1) fx_fft_pass<1>(x, size, L, st, tw, lane);
 }
 
 constexpr int kFxMaxNfft = 1024;
 
+template <int NFFT>
 __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedTables t,
                                                           int16_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // per wave (nothing is shared between waves): uint32 x[nfft] packed (re, im); uint32 P[nfft/2]; int mel[64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nfft = t.nfft;
-    uint32_t *x = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * nfft;
-    uint32_t *P = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(uint32_t)) +
+    constexpr int nfft = NFFT;
+    constexpr int xw = nfft + nfft / 32;                       // padded FFT buffer (fxi)
+    uint32_t *x = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * xw;
+    uint32_t *P = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * xw * sizeof(uint32_t)) +
                   (size_t)wave * (nfft / 2);
-    int *melv = reinterpret_cast<int *>(smem + (size_t)kWavesPerBlock * nfft * sizeof(uint32_t) +
+    int *melv = reinterpret_cast<int *>(smem + (size_t)kWavesPerBlock * xw * sizeof(uint32_t) +
                                         (size_t)kWavesPerBlock * (nfft / 2) * sizeof(uint32_t)) +
                 wave * kMaxMel;
+    // the filterbank weights, once per workgroup (the loop over a filter's taps would otherwise wait for a global
+    // load per tap: at 16 filters and nfft 1024 that was most of the kernel's time)
+    uint32_t *melw = reinterpret_cast<uint32_t *>(smem + (size_t)kWavesPerBlock * (xw + nfft / 2 + kMaxMel) * sizeof(uint32_t));
+    for (int i = threadIdx.x; i < t.mel_w_total; i += kBlock) melw[i] = t.mel_w[i];
+    // ... and both twiddle ROMs: a butterfly's twiddle out of global memory is a load the whole stage waits for
+    // (28 dependent round trips per frame at nfft 256: SQ_WAIT_ANY was 59 % of the wave cycles)
+    uint2 *tw1 = reinterpret_cast<uint2 *>(melw + ((t.mel_w_total + 1) & ~1));
+    uint2 *tw2 = tw1 + nfft / 2;
+    for (int i = threadIdx.x; i < nfft / 2; i += kBlock) tw1[i] = t.tw_fft[i];
+    for (int i = threadIdx.x; i < 2 * t.n_mel; i += kBlock) tw2[i] = t.tw_dct[i];
+    __syncthreads();
 
+    // frame cursor of this wave: (ch, f), advanced by the number of waves in the grid without a division (a 64-bit
+    // division per frame cost as many instructions as a 256-point FFT)
     const long long waves_total = (long long)gridDim.x * kWavesPerBlock;
-    const long long iters = (s.total_frames + waves_total - 1) / waves_total;
-    const int L = t.log2_nfft;
+    const long long step_ch = waves_total / s.frames_per_ch, step_f = waves_total % s.frames_per_ch;
+    constexpr int L = __builtin_ctz(NFFT);
+    long long fid = (long long)blockIdx.x * kWavesPerBlock + wave;
+    long long ch = fid / s.frames_per_ch, f = fid % s.frames_per_ch;
 
-    for (long long it = 0; it < iters; ++it) {
-        const long long fid = it * waves_total + (long long)blockIdx.x * kWavesPerBlock + wave;
-        const bool valid = fid < s.total_frames;
-        const long long ch = valid ? fid / s.frames_per_ch : 0;
-        const long long f = valid ? fid % s.frames_per_ch : 0;
+    for (; fid < s.total_frames; fid += waves_total, ch += step_ch, f += step_f) {
+        if (f >= s.frames_per_ch) {
+            f -= s.frames_per_ch;
+            ++ch;
+        }
+        const bool valid = true;
         const int16_t *base = s.pcm + ch * s.ch_stride;
         const long long n0 = f * (long long)s.hop;
 
@@ -298,7 +389,9 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
         // fft.py:413-424 bit-reversed load, imag = 0
         // frames that lie inside the stream (all but the first and the padded tail) take plain loads
         const bool inside = valid && n0 - 1 >= -(long long)s.halo && n0 + nfft <= s.n_samples;
-        for (int i = lane; i < nfft; i += 64) {
+#pragma unroll 4
+        for (int i0 = 0; i0 < nfft; i0 += 64) {
+            const int i = i0 + lane;
             int x0, o;
             if (inside) {
                 x0 = base[n0 + i];
@@ -310,37 +403,52 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
             int y = wrap16(x0 + (o >> 5) - o);
             int w = __mul24(y, t.curve[i]) >> 9;
             int r = (int)(__brev((unsigned)i) >> (32 - L));
-            x[r] = (uint32_t)w & 0xffffu;
+            x[fxi(r)] = (uint32_t)w & 0xffffu;
         }
         wave_sync();
-        fx_fft_inplace(x, nfft, L, t.tw_fft, lane);
+        fx_fft_ct<L, 0>(x, tw1, lane);
 
         // pow2.py:32,64  (re^2 + im^2) >> 2, 30 bits
-        for (int k = lane; k < nfft / 2; k += 64) {
-            const int re = (int)(short)(x[k] & 0xffffu), im = (int)x[k] >> 16;
+#pragma unroll 4
+        for (int k0 = 0; k0 < nfft / 2; k0 += 64) {
+            const int k = k0 + lane;
+            const uint32_t xk = x[fxi(k)];
+            const int re = (int)(short)(xk & 0xffffu), im = (int)xk >> 16;
             uint32_t r = (uint32_t)(re * re) + (uint32_t)(im * im);
             P[k] = r >> 2;
         }
         wave_sync();
 
-        // filterbank.py:88-142 in closed form (tables.hpp: fx_mel), then log.py Log2Fix(16, 15)
-        if (lane < t.n_mel) {
-            const int st = t.mel_start[lane], cnt = t.mel_count[lane];
-            const uint32_t *w = t.mel_w + t.mel_off[lane];
+        // filterbank.py:88-142 in closed form (tables.hpp: fx_mel), then log.py Log2Fix(16, 15).  64 / n_mel lanes
+        // share a filter (lane = part * n_mel + filter), each sums every (64 / n_mel)-th of its taps out of the LDS copy
+        // of the weights; 64-bit integer partial sums are exact, so their order does not matter
+        {
+            const int f = lane & (t.n_mel - 1), part = lane >> t.log2_mel, parts = 64 >> t.log2_mel;
+            const int st = t.mel_start[f], cnt = t.mel_count[f];
+            const uint32_t *w = melw + t.mel_off[f];
             unsigned long long acc = 0;
-            for (int j = 0; j < cnt; ++j) acc += (unsigned long long)P[st + j] * (unsigned long long)w[j];
-            unsigned v = (unsigned)(acc >> t.mel_shift) & 0xFFFFu;
-            // Turner log2, Q4.11: precision 11, 10 squarings (log.py:33-102)
-            unsigned xx = (v ? v : 1u) << 11;
-            unsigned o = 0;
-            while (xx >= (1u << 12)) { xx >>= 1; o += 1u << 11; }
-            unsigned z = xx, b = 1u << 10;
-            for (int c = 0; c < 10; ++c) {
-                unsigned cc = z * z;
-                if (cc & (1u << 23)) { z = cc >> 12; o += b; } else { z = cc >> 11; }
-                b >>= 1;
+#pragma unroll 4
+            for (int j = part; j < cnt; j += parts) acc += (unsigned long long)P[st + j] * (unsigned long long)w[j];
+            for (int o = t.n_mel; o < 64; o <<= 1) {
+                const unsigned lo = __shfl_xor((unsigned)acc, o, 64), hi = __shfl_xor((unsigned)(acc >> 32), o, 64);
+                acc += ((unsigned long long)hi << 32) | lo;
             }
-            melv[lane] = (int)(o & 0x7FFFu);
+            if (lane < t.n_mel) {
+                unsigned v = (unsigned)(acc >> t.mel_shift) & 0xFFFFu;
+                // Turner log2, Q4.11: precision 11, 10 squarings (log.py:33-102); the normalisation loop as one clz
+                unsigned xx = (v ? v : 1u) << 11;
+                const int sh = (32 - 12) - __clz(xx) > 0 ? (32 - 12) - __clz(xx) : 0;       // xx >= 2^12  <=>  sh > 0
+                unsigned o = (unsigned)sh << 11;
+                xx >>= sh;
+                unsigned z = xx, b = 1u << 10;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {
+                    unsigned cc = z * z;
+                    if (cc & (1u << 23)) { z = cc >> 12; o += b; } else { z = cc >> 11; }
+                    b >>= 1;
+                }
+                melv[lane] = (int)(o & 0x7FFFu);
+            }
         }
         wave_sync();
 
@@ -353,11 +461,16 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
                 v = melv[n];
             }
             int r = (int)(__brev((unsigned)i) >> (32 - t.log2_dct));
-            x[r] = (uint32_t)v & 0xffffu;
+            x[fxi(r)] = (uint32_t)v & 0xffffu;
         }
         wave_sync();
-        fx_fft_inplace(x, dsz, t.log2_dct, t.tw_dct, lane);
-        if (valid && lane < t.n_cep) out[fid * t.n_cep + lane] = (int16_t)(x[lane] & 0xffffu);
+        switch (t.log2_dct) {                         // 4 n_mel points: compile-time sizes for the usual filter counts
+            case 6: fx_fft_ct<6, 0>(x, tw2, lane); break;
+            case 7: fx_fft_ct<7, 0>(x, tw2, lane); break;
+            case 8: fx_fft_ct<8, 0>(x, tw2, lane); break;
+            default: fx_fft_inplace(x, dsz, t.log2_dct, tw2, lane); break;
+        }
+        if (valid && lane < t.n_cep) out[fid * t.n_cep + lane] = (int16_t)(x[fxi(lane)] & 0xffffu);
         wave_sync();
     }
 }

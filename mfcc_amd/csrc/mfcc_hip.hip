@@ -312,6 +312,7 @@ int build_tables(mfcc_hip_handle *h) {
     h->ft.mel_count = reinterpret_cast<const int *>(b + o_mc);
     h->ft.mel_off = reinterpret_cast<const int *>(b + o_mo);
     h->ft.mel_w = reinterpret_cast<const float *>(b + o_mw);
+    h->ft.mel_w_total = (int)melw.size();
     h->ft.dct = reinterpret_cast<const float *>(b + o_dct);
     h->ft.window_d = dc_exact ? reinterpret_cast<const double *>(b + o_wd) : nullptr;
     h->ft.n_mel = r.n_mel;
@@ -324,7 +325,9 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.mel_count = reinterpret_cast<const int *>(b + o_xc);
         h->xt.mel_off = reinterpret_cast<const int *>(b + o_xo);
         h->xt.mel_w = reinterpret_cast<const uint32_t *>(b + o_xw);
+        h->xt.mel_w_total = x5_w_total;
         h->xt.mel_shift = fm.shift;
+        h->xt.log2_mel = ilog2(r.n_mel);
         h->xt.nfft = r.nfft;
         h->xt.log2_nfft = ilog2(r.nfft);
         h->xt.n_mel = r.n_mel;
@@ -381,9 +384,25 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         long long cap = (long long)h->n_cu * 8;
         if (blocks > cap) blocks = cap;
         size_t lds = size_t(mfcc_k::kWavesPerBlock) *
-                     (size_t(h->r.nfft) * sizeof(uint32_t) + size_t(h->r.nfft / 2) * 4 + mfcc_k::kMaxMel * 4);
-        hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds,
-                           h->stream, s, h->xt, static_cast<int16_t *>(d_out));
+                         (size_t(h->r.nfft + h->r.nfft / 32) * sizeof(uint32_t) + size_t(h->r.nfft / 2) * 4 + mfcc_k::kMaxMel * 4) +
+                     size_t((h->xt.mel_w_total + 1) & ~1) * sizeof(uint32_t) +            // filterbank weights,
+                     (size_t(h->r.nfft / 2) + size_t(2 * h->r.n_mel)) * sizeof(uint2);     // both twiddle ROMs
+        int16_t *o = static_cast<int16_t *>(d_out);
+        switch (h->r.nfft) {
+#define MFCC_FX_CASE(N)                                                                                            \
+    case N:                                                                                                        \
+        hipLaunchKernelGGL(mfcc_k::mfcc_fixed_kernel<N>, dim3((unsigned)blocks), dim3(mfcc_k::kBlock), lds, h->stream, \
+                           s, h->xt, o);                                                                           \
+        break;
+            MFCC_FX_CASE(64)
+            MFCC_FX_CASE(128)
+            MFCC_FX_CASE(256)
+            MFCC_FX_CASE(512)
+            MFCC_FX_CASE(1024)
+#undef MFCC_FX_CASE
+            default:
+                return MFCC_HIP_ERROR_UNSUPPORTED;
+        }
     } else if (use_fused(h)) {
         if (!mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;

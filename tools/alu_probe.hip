@@ -11,7 +11,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum Op { NONE = 0, FMA32, PKFMA, PKADD, FMA64, CVT64, MFMA, LOG, DOT2, MFMABF, CVTBF, LDSR, MIX2, MIX4, MIX6, MIX8, MIXB4, MIXF4, MIXF8, MIXD4, MIXBF4, MIXBF8, MIXC4 };
+enum Op { NONE = 0, FMA32, PKFMA, PKADD, FMA64, CVT64, MFMA, LOG, DOT2, MFMABF, CVTBF, LDSR, MIX2, MIX4, MIX6, MIX8, MIXB4, MIXF4, MIXF8, MIXD4, MIXBF4, MIXBF8, MIXC4, SALU, SALUDEP, PKSALU, BRANCH };
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int OP>
@@ -19,6 +19,7 @@ __device__ __forceinline__ void stream(int iters, float seed, float *sink) {
     if constexpr (OP == NONE) return;
     float a[16]; v2f p[16]; double d[16]; f32x4 acc[8]; int q[16];
     bf16x8 hb = {1, 2, 3, 4, 5, 6, 7, 8};
+    int sg[8] = {1, 2, 3, 4, 5, 6, 7, 8};
 #pragma unroll
     for (int i = 0; i < 16; ++i) { a[i] = seed + i; p[i] = (v2f){seed + i, seed - i}; d[i] = seed + i; q[i] = (int)seed + i; }
 #pragma unroll
@@ -58,11 +59,20 @@ __device__ __forceinline__ void stream(int iters, float seed, float *sink) {
                         else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[(i + j) & 15]) : "v"(c));
                     }
                 }
+                if constexpr (OP == SALU) asm volatile("s_add_u32 s40, s41, 1\n\ts_add_u32 s42, s43, 1\n\ts_add_u32 s44, s45, 1\n\ts_add_u32 s46, s47, 1" ::: "s40", "s42", "s44", "s46", "scc");
+                if constexpr (OP == SALUDEP) asm volatile("s_add_u32 s40, s40, 1\n\ts_add_u32 s40, s40, 1\n\ts_add_u32 s40, s40, 1\n\ts_add_u32 s40, s40, 1" ::: "s40", "scc");
+                if constexpr (OP == PKSALU) {        // one packed op and two independent scalar ops: "instr" = the group
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(c2));
+                    asm volatile("s_add_u32 s40, s41, 1\n\ts_add_u32 s42, s43, 1" ::: "s40", "s42", "scc");
+                }
+                if constexpr (OP == BRANCH) asm volatile("s_cmp_lg_u32 %0, 0x7fffffff\n\ts_cbranch_scc1 1f\n\ts_nop 0\n1:" : : "s"(sg[0]) : "scc");
                 if constexpr (OP == MFMA) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i & 7]) : "v"(a[i]), "v"(c));
             }
         }
     }
     float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (float)sg[i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y + (float)d[i] + (float)q[i];
 #pragma unroll
@@ -139,6 +149,11 @@ int main() {
     run<MIXBF8, NONE>("[mfma_bf16 + 8 fma32] alone", it, sink, cyc);
     run<MIXF4, MIXF4>("[mfma + 4 fma32] || same", it, sink, cyc);
     run<MIXF4, PKFMA>("[mfma + 4 fma32] || pk_fma", it, sink, cyc);
+    run<SALU, NONE>("4 x s_add (independent)", it, sink, cyc);
+    run<SALUDEP, NONE>("4 x s_add (one chain)", it, sink, cyc);
+    run<PKSALU, NONE>("[pk_fma + 2 s_add] alone", it, sink, cyc);
+    run<BRANCH, NONE>("[s_cmp + taken branch] alone", it, sink, cyc);
+    run<SALU, PKFMA>("s_add || pk_fma", it, sink, cyc);
     run<CVTBF, NONE>("cvt_pk_bf16_f32 alone", it, sink, cyc);
     run<CVTBF, CVTBF>("cvt_pk_bf16 || same", it, sink, cyc);
     run<MFMABF, NONE>("mfma16x16x32bf16 alone", it, sink, cyc);
