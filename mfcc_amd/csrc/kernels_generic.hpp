@@ -412,6 +412,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_fixed_kernel(StreamDesc s, FixedT
 #pragma unroll 4
         for (int k0 = 0; k0 < nfft / 2; k0 += 64) {
             const int k = k0 + lane;
+            if (nfft / 2 < 64 && k >= nfft / 2) break;           // nfft 64: half a wave
             const uint32_t xk = x[fxi(k)];
             const int re = (int)(short)(xk & 0xffffu), im = (int)xk >> 16;
             uint32_t r = (uint32_t)(re * re) + (uint32_t)(im * im);

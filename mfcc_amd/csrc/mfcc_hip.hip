@@ -70,8 +70,11 @@ size_t count_frames(const Resolved &r, size_t n) {
 bool fixed_supported(const Resolved &r) {
     // RTL constraints: FFT sizes are powers of two (mfcc/misc/fft.py:351-353) for both the
     // nfft-point FFT and the (4 * nfilters)-point DCT FFT; hop = nfft // 3 (mfcc/core/mfcc.py:43)
-    return is_pow2(4 * r.n_mel) && 4 * r.n_mel <= r.nfft && r.n_mel >= 4 && r.hop == r.nfft / 3 &&
-           r.nfft >= 64;
+    if (!(is_pow2(4 * r.n_mel) && 4 * r.n_mel <= r.nfft && r.n_mel >= 4 && r.hop == r.nfft / 3 && r.nfft >= 64))
+        return false;
+    // filter points too dense for the streaming filterbank's ramp logic (filterbank.py:22-34, 88-142): the RTL then
+    // emits fewer than n_mel values per frame and the frame structure falls apart -- not a configuration to reproduce
+    return fx_mel(r.nfft, r.n_mel, double(r.sample_rate)).n_out == r.n_mel;
 }
 
 struct SparseRows {

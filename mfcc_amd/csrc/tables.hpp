@@ -152,6 +152,8 @@ inline void fx_twiddles(int size, std::vector<int> &re, std::vector<int> &im) {
 }
 
 struct FxMel {
+    int n_out;                       // values the streaming filterbank emits per frame (must be n_mel; fewer when the
+                                     // filter points are too dense for its ramp logic)
     int shift;                       // right shift of the 64-bit accumulator
     std::vector<uint32_t> dense;     // [n_mel][nfft/2], weights x 2^-30
 };
@@ -189,12 +191,14 @@ inline FxMel fx_mel(int nfft, int n_mel, double sample_rate) {
     m.dense.assign(size_t(n_mel) * nb, 0u);
     unsigned long long acc = 0;
     int adr = 0;
+    m.n_out = 0;
     const unsigned long long top = (1ull << wsize) - 1;
     for (int k = 0; k < nb; ++k) {
         bool last = (k == nb - 1);
         unsigned long long b = acc >> wsize;
         bool hi = (b == top);
         if (hi || last) {
+            if (adr != 0) ++m.n_out;                     // filterbank.py:136-142: an event with adr != 0 emits
             if (!last && adr < n_mel) m.dense[size_t(adr) * nb + k] = 1u << wsize;
             adr = last ? 0 : adr + 1;
             acc = 0;

@@ -212,20 +212,21 @@ def test_fused1024_kernel_alignment_shifts_and_edges(mfcc_amd):
     assert e_max <= TOL and e_l2 <= TOL
 
 
-@pytest.mark.parametrize("ncep", [1, 13, 16])
+@pytest.mark.parametrize("ncep", [1, 13, 16, 17, 32, 40])
 def test_fused1024_other_ncep_stream_padding_and_lifter(mfcc_amd, ncep):
     pcm = np.stack([mf.synth_pcm(341 * 40 + 1024 + 55, seed=300 + s) for s in range(3)])
     ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream", nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
     with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=ncep, power_scale=0, pad_mode="stream") as m:
-        assert m.kernel_name().endswith("fused1024_kernel")
+        # up to 32 coefficients (what the reference tops keep, main.c:13) on the fused kernel; beyond: generic
+        assert m.kernel_name().endswith("fused1024_kernel" if ncep <= 32 else "generic_kernel")
         got = m.process(pcm)
         many = m.process_batch([pcm[0], pcm[1][:5000], pcm[2][:1023]])
         assert np.array_equal(many[0], got[0]) and many[2].shape == (1, ncep)
     assert got.shape == ref.shape
     e_max, e_l2 = _err(got, ref)
     assert e_max <= TOL and e_l2 <= TOL
-    if ncep == 16:
-        with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=16, power_scale=0, pad_mode="stream", lifter=22.0) as m:
+    if ncep in (16, 32):
+        with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=ncep, power_scale=0, pad_mode="stream", lifter=22.0) as m:
             lif = m.process(pcm)
         e_max, e_l2 = _err(lif, np.stack([mf.lifter(r, 22) for r in ref]))
         assert e_max <= TOL and e_l2 <= TOL
@@ -384,11 +385,24 @@ def test_fixed_bit_exact_config3_full_size(mfcc_amd):
 
 def test_fixed_other_parameters(mfcc_amd):
     pcm = mf.synth_pcm(20000, seed=9)
-    for nfft, nfil, ncep in [(256, 16, 16), (1024, 64, 32), (512, 16, 16)]:
+    for nfft, nfil, ncep in [(256, 16, 16), (1024, 64, 32), (512, 16, 16), (256, 32, 13), (1024, 32, 32),
+                             (128, 16, 16), (128, 8, 8), (64, 8, 8), (1024, 16, 5), (256, 8, 8)]:
         ref = mx.mfcc_fixed_ref(pcm, nfft=nfft, nfilters=nfil, nceptrums=ncep)
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nfil, nceptrums=ncep, pad_mode="stream") as m:
             got = m.process_fixed(pcm)
         assert np.array_equal(got, ref), (nfft, nfil, ncep)
+
+
+def test_fixed_filterbanks_the_rtl_cannot_stream_are_refused(mfcc_amd):
+    """Filter points too dense for the streaming filterbank (filterbank.py:22-34,88-142): the RTL would emit fewer
+    than n_mel values per frame (the oracle asserts on exactly these sets) -- UNSUPPORTED, never a made-up result."""
+    for nfft, nfil in [(256, 64), (512, 64), (128, 32), (64, 16)]:
+        with pytest.raises(AssertionError):
+            mx.mfcc_fixed_ref(mf.synth_pcm(2000, seed=1), nfft=nfft, nfilters=nfil, nceptrums=4)
+        with mfcc_amd.MFCC(nfft=nfft, nfilters=nfil, nceptrums=4, power_scale=0) as m:
+            with pytest.raises(mfcc_amd.MfccHipError) as e:
+                m.process_fixed(np.zeros(4000, np.int16))
+            assert e.value.code == -105
 
 
 def test_fixed_unsupported_is_an_error_not_a_fallback(mfcc_amd):
