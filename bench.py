@@ -341,7 +341,7 @@ def bench_config2(cx, args):
         }
         if valu:
             line["valu_roofline"] = valu_roofline(torch, dev, frames, kernel_ms, valu, src)
-            if PROFILE["mfma_per_frame"] and kname.endswith("fused512_kernel"):
+            if PROFILE["mfma_per_frame"] and kname.startswith("mfcc_fused512"):
                 line["alu_roofline"] = alu_roofline(torch, dev, frames, kernel_ms, valu, PROFILE["mfma_per_frame"], src)
         if pcie:
             line["pcie_inclusive"] = pcie

@@ -1,0 +1,379 @@
+// Fused 512/170/32 float kernel, TWELVE-wave form: the same arithmetic, codelets and tables as
+// kernel_fused512.hpp (read its header first), re-staged so that every SIMD always has three waves in
+// three DIFFERENT phases of the pipeline.
+//
+// Why.  Measured on the 4-wave form (profiles/r02_*, tools/alu_probe.hip): a wave issues one instruction per
+// ~5 clocks whatever its type, so a tile costs a wave its ~460 instructions x 5 clocks plus MFMA / LDS / barrier
+// waits = 5 300 clocks, and with 203 VGPRs only two such waves fit on a SIMD: its fp32 pipe idles ~60 % of the
+// time.  Three waves per SIMD need <= 168 VGPRs; six-wave workgroups do not co-reside (tools/occ_probe.hip: the
+// dispatcher places waves on SIMDs cyclically), so it is ONE workgroup of twelve waves per CU:
+//
+//   waves 0..3   group A: the four workers of a 16-frame tile (pass 1 / pass 2 / mel, nothing else)
+//   waves 4..7   group B: the four workers of ANOTHER tile, half a period behind A
+//   waves 8, 9   fetch the sample windows from HBM one half-step ahead and park them (pre-emphasised fp32)
+//   wave  10     column 16 of the group that is in pass 2: 16 x 16 DFT + its mel contribution (fp32 MFMAs)
+//   wave  11     the tail of the tile that finished pass 2 in the previous half-step: log2, DCT-II, store
+//
+// Waves i, i + 4 and i + 8 share SIMD i's slot (cyclic placement): one worker in pass 1, one in pass 2, one helper.
+// Registers: a worker without the helpers' state needs 156 VGPRs (164 with the dense mel sets).
+//
+// Time runs in HALF-STEPS h = 0, 1, 2, ... separated by ONE workgroup barrier each:
+//   group A: pass 1 of its tile k at h = 2 k,     pass 2 + mel at h = 2 k + 1
+//   group B: pass 1 of its tile k at h = 2 k + 1, pass 2 + mel at h = 2 k + 2
+//   parkers: at h they park the window fetched during h - 1: S_B(h / 2) for even h, S_A((h + 1) / 2) for odd h
+//            (a group's window is rewritten while that group is in pass 2 and nobody reads it)
+//   column 16 at h: the group in pass 2 (its V was written in h - 1); its partial sums go to Q slot 4 of the group
+//   tail at h: the group that was in pass 2 at h - 1 (Q complete at the barrier; rewritten only at h + 1)
+// LDS (114.5 KB): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
+// 2 w, group B 2 w + 1 of the 4-wave form's tile order.
+#pragma once
+
+#include "kernel_fused512.hpp"
+
+namespace mfcc_fused12 {
+
+using namespace mfcc_fused;
+
+constexpr int kW12Waves = 12;
+constexpr int kQSlots = 5;                          // 4 workers + column 16
+constexpr int kQGroupWords = kQSlots * 2 * 256;
+constexpr int kGroupWords = kTile * kTFrame + kTile * kVStride + kQGroupWords + kSUsed;
+constexpr int kW12LdsWords = 2 * kGroupWords;
+constexpr int kParkers = 128, kParkPieces = 3;      // waves 8, 9: 128 lanes x 3 pieces of 8 samples = the 3072-slot window
+static_assert(kParkers * kParkPieces * 8 == kSUsed, "window pieces");
+
+struct Fetch3 {
+    i32x4 v[kParkPieces];
+    int p[kParkPieces];          // dword in front of v[k]: its high half is the piece's predecessor sample
+};
+
+__device__ __forceinline__ void fetch_window3(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch3 &f) {
+    if (w.inside) {
+        const i32x4 *g = reinterpret_cast<const i32x4 *>(w.ptr - w.shift);
+        const int *g32 = reinterpret_cast<const int *>(g);
+#pragma unroll
+        for (int k = 0; k < kParkPieces; ++k) {
+            f.v[k] = g[k * kParkers + u];
+            f.p[k] = g32[4 * (k * kParkers + u) - 1];
+        }
+    } else {
+        const long long first = (long long)w.t_in * kTileHop;      // channel-relative
+        const int16_t *base = w.ptr - first;
+#pragma unroll
+        for (int k = 0; k < kParkPieces; ++k) {
+            int h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = mfcc_k::sample_at_i(s, base, first + 8 * (k * kParkers + u) + j) & 0xFFFF;
+            f.v[k] = (i32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+            f.p[k] = mfcc_k::sample_at_i(s, base, first + 8 * (k * kParkers + u) - 1) << 16;
+        }
+    }
+}
+
+__device__ __forceinline__ void park_window3(float *Sf, int u, const Fetch3 &f) {
+#pragma unroll
+    for (int k = 0; k < kParkPieces; ++k) preemph8(f.p[k], f.v[k], Sf + 8 * (k * kParkers + u));
+}
+
+// cursor of virtual workgroup v
+__device__ __forceinline__ Cursor cursor_of(const mfcc_k::StreamDesc &s, const LaunchGeom &g, unsigned v) {
+    Cursor c;
+    c.ch = (int)(v / (unsigned)g.tiles_per_ch);
+    c.t_in = (int)(v - (unsigned)c.ch * (unsigned)g.tiles_per_ch);
+    c.ptr = s.pcm + (long long)c.ch * s.ch_stride + (long long)c.t_in * kTileHop;
+    return c;
+}
+
+#ifndef MFCC_W12_PRIO_P1
+#define MFCC_W12_PRIO_P1 1
+#endif
+#ifndef MFCC_W12_PRIO_P2
+#define MFCC_W12_PRIO_P2 0
+#endif
+
+// Diagnostic build only (-DMFCC_W12_STAMPS): per wave, the clocks spent working (loop top -> barrier) and the clocks of
+// the whole loop, summed over workgroups; written to a buffer nothing else reads.
+#ifdef MFCC_W12_STAMPS
+__device__ unsigned long long g_stamps12[kW12Waves * 4];      // [wave]: work even h, work odd h, total, half-steps
+#define W12_LOOP_BEGIN unsigned long long w12_work[2] = {0, 0}, w12_t0, w12_begin = __builtin_amdgcn_s_memtime(); int w12_n = 0;
+#define W12_T0 w12_t0 = __builtin_amdgcn_s_memtime();
+#define W12_T1(h) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); w12_work[(h) & 1] += __builtin_amdgcn_s_memtime() - w12_t0; ++w12_n; } while (0)
+#define W12_LOOP_END do { if (lane == 0) { atomicAdd(&g_stamps12[wave * 4 + 0], w12_work[0]); atomicAdd(&g_stamps12[wave * 4 + 1], w12_work[1]); \
+    atomicAdd(&g_stamps12[wave * 4 + 2], __builtin_amdgcn_s_memtime() - w12_begin); atomicAdd(&g_stamps12[wave * 4 + 3], (unsigned long long)w12_n); } } while (0)
+#else
+#define W12_LOOP_BEGIN
+#define W12_T0
+#define W12_T1(h)
+#define W12_LOOP_END
+#endif
+
+template <bool DENSE>
+__global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
+    constexpr int kSets = SetsBf<DENSE>::N;
+    __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;         // 0: A, 1: B, 2: helpers
+    const int wi = wave & 3;
+    const int lo = lane & 15;
+    const int q = lane >> 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    auto Tt = [&](int gi) { return lds + gi * kGroupWords; };
+    auto Vt = [&](int gi) { return lds + gi * kGroupWords + kTile * kTFrame; };
+    auto Qt = [&](int gi) { return lds + gi * kGroupWords + kTile * kTFrame + kTile * kVStride; };
+    auto Sf = [&](int gi) { return lds + gi * kGroupWords + kTile * kTFrame + kTile * kVStride + kQGroupWords; };
+
+    // tiles of the two groups: virtual workgroups 2 w and 2 w + 1 of a grid of 2 x gridDim.x
+    const unsigned va = 2u * blockIdx.x, vb = va + 1u;
+    const int n_tiles = g.tiles_per_ch * g.n_ch;                       // < 2^31 (host check)
+    const int gv = 2 * (int)gridDim.x;
+    const int nA = (int)va < n_tiles ? (n_tiles - (int)va + gv - 1) / gv : 0;
+    const int nB = (int)vb < n_tiles ? (n_tiles - (int)vb + gv - 1) / gv : 0;
+    const int last_h = 2 * nA + 1;                                     // B's last tail (nB <= nA) is at 2 nB + 1
+
+    if (grp < 2) {
+        // =========================================================================== workers
+        const int gi = grp;
+        const int fr_id = wi + 8 * (q & 1) + 4 * (q >> 1);
+        using mfcc_codelets::v2f;
+        v2f wp[16], tw[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wp[i] = reinterpret_cast<const v2f *>(t.win)[lo * 16 + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tw[i] = reinterpret_cast<const v2f *>(t.tw)[lo * 16 + i];
+        u32x4 ah[kSets], al[kSets];
+#pragma unroll
+        for (int st = 0; st < kSets; ++st)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                ah[st][d] = t.a_mel_bf[((wi * kSets + st) * 2 + 0) * 256 + d * 64 + lane];
+                al[st][d] = t.a_mel_bf[((wi * kSets + st) * 2 + 1) * 256 + d * 64 + lane];
+            }
+        float *const T = Tt(gi), *const V = Vt(gi), *const Q = Qt(gi), *const S = Sf(gi);
+        const int lane_slot = fr_id * kHop + lo;
+        const int n_mine = gi ? nB : nA;
+        Cursor cur = cursor_of(s, g, gi ? vb : va);
+
+        lds_barrier();                                 // the parkers' prologue: S_A(0) is in LDS
+        W12_LOOP_BEGIN
+        for (int h = 0; h <= last_h; ++h) {
+            W12_T0
+            const int rel = h - gi;                    // >= 0: pass 1 of tile rel / 2 (rel even), pass 2 of (rel - 1) / 2 (odd)
+            if (rel >= 0 && !(rel & 1) && (rel >> 1) < n_mine) {
+                // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
+                // (the longer of the two phases: it gets the SIMD's issue priority over the partner group's pass 2,
+                // whichever of the two waves is older -- measured: 2000 clocks per half-step instead of 2400)
+                __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P1);
+                const int shift = window_of(cur, g).shift;
+                v2f ep[16];
+                {
+                    const float *sp = S + lane_slot + shift;
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
+                }
+                v2f ty[16];
+                float y16;
+                mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
+                v2f *trow = reinterpret_cast<v2f *>(T + fr_id * kTFrame + lo * kTRow);
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
+                V[fr_id * kVStride + lo] = y16;
+            } else if (rel >= 1 && (rel & 1) && ((rel - 1) >> 1) < n_mine) {
+                // ---------------- pass 2: complex FFT-16 over n2 for frame lo, column k1 = 4 wi + q; mel MFMAs
+                __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P2);
+                float pw[16];
+                {
+                    v2f x[16], z[16];
+                    const v2f *tcol = reinterpret_cast<const v2f *>(T + lo * kTFrame + 2 * (4 * wi + q));
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
+                    mfcc_codelets::cfft16(x, z);
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
+                }
+                PowerBf pb;
+                split_power(pw, pb);
+                f32x4 acc[kSets];
+#pragma unroll
+                for (int st = 0; st < kSets; ++st) acc[st] = zero;
+                mel_bf_all<DENSE, 0>(ah, al, pb, acc, [](auto) {});
+                f32x4 b0, b1;
+                mel_bf_blocks<DENSE>(acc, b0, b1);
+                *reinterpret_cast<f32x4 *>(Q + (2 * wi + 0) * 256 + lane * 4) = b0;
+                *reinterpret_cast<f32x4 *>(Q + (2 * wi + 1) * 256 + lane * 4) = b1;
+                advance(cur, g);
+            }
+            W12_T1(h);
+            lds_barrier();
+        }
+        W12_LOOP_END;
+    } else if (wi < 2) {
+        // =========================================================================== parkers (waves 8, 9)
+        const int u = wi * 64 + lane;                  // 0..127
+        // the youngest waves of the workgroup lose the issue arbitration against the eight workers (priority, then age)
+        // although they have the least to do and everybody waits for them at the barrier
+        __builtin_amdgcn_s_setprio(3);
+        Cursor pa = cursor_of(s, g, va), pb = cursor_of(s, g, vb);
+        int ka = 0, kb = 0;                            // next tile of each stream to fetch
+        // one register set per stream: a window is fetched TWO half-steps before it is parked (HBM latency under
+        // load is longer than a half-step), i.e. right after the same stream's previous window has been parked
+        Fetch3 fa, fb;
+        bool have_a = false, have_b = false;
+        if (nA > 0) {                                  // prologue: S_A(0) directly
+            fetch_window3(s, window_of(pa, g), u, fa);
+            park_window3(Sf(0), u, fa);
+            advance(pa, g);
+            ++ka;
+        }
+        if (nB > 0) {                                  // S_B(0): parked at h = 0
+            fetch_window3(s, window_of(pb, g), u, fb);
+            advance(pb, g);
+            ++kb;
+            have_b = true;
+        }
+        if (ka < nA) {                                 // S_A(1): parked at h = 1
+            fetch_window3(s, window_of(pa, g), u, fa);
+            advance(pa, g);
+            ++ka;
+            have_a = true;
+        }
+        lds_barrier();                                 // S_A(0) is parked: h = 0 may start
+        W12_LOOP_BEGIN
+        for (int h = 0; h <= last_h; ++h) {
+            W12_T0
+            if (h & 1) {                               // odd h: S_A((h + 1) / 2), then fetch S_A((h + 3) / 2) for h + 2
+                if (have_a) park_window3(Sf(0), u, fa);
+                have_a = false;
+                if (ka < nA) {
+                    fetch_window3(s, window_of(pa, g), u, fa);
+                    advance(pa, g);
+                    ++ka;
+                    have_a = true;
+                }
+            } else {                                   // even h: S_B(h / 2), then fetch S_B(h / 2 + 1) for h + 2
+                if (have_b) park_window3(Sf(1), u, fb);
+                have_b = false;
+                if (kb < nB) {
+                    fetch_window3(s, window_of(pb, g), u, fb);
+                    advance(pb, g);
+                    ++kb;
+                    have_b = true;
+                }
+            }
+            W12_T1(h);
+            lds_barrier();
+        }
+        W12_LOOP_END;
+    } else if (wi == 2) {
+        // =========================================================================== column 16 (wave 10)
+        __builtin_amdgcn_s_setprio(3);
+        float ax[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ax[i] = t.a_extra[(1 * kAextra + i) * 64 + lane];
+        lds_barrier();                                 // matches the parkers' prologue barrier
+        W12_LOOP_BEGIN
+        for (int h = 0; h <= last_h; ++h) {
+            W12_T0
+            // the group in pass 2 at h: A (tile (h - 1) / 2) for odd h, B (tile h / 2 - 1) for even h >= 2
+            const int gi = (h & 1) ? 0 : 1;
+            const int k = (h & 1) ? (h - 1) / 2 : h / 2 - 1;
+            if (k >= 0 && k < (gi ? nB : nA)) {
+                const float *V = Vt(gi);
+                float *Q = Qt(gi);
+                const float v0 = V[lo * kVStride + 0 + q], v1 = V[lo * kVStride + 4 + q];
+                const float v2 = V[lo * kVStride + 8 + q], v3 = V[lo * kVStride + 12 + q];
+                f32x4 sp = MFCC_MFMA(ax[0], v0, zero);
+                f32x4 sp2 = MFCC_MFMA(ax[1], v1, zero);
+                sp = MFCC_MFMA(ax[2], v2, sp);
+                sp2 = MFCC_MFMA(ax[3], v3, sp2);
+                sp += sp2;
+                const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);      // bin 16 + 64 q
+                const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);      // bin 48 + 64 q
+                const f32x4 x0 = MFCC_MFMA(ax[4], s0, zero), y0 = MFCC_MFMA(ax[5], s1, zero);
+                const f32x4 x1 = MFCC_MFMA(ax[6], s0, zero), y1 = MFCC_MFMA(ax[7], s1, zero);
+                *reinterpret_cast<f32x4 *>(Q + (2 * 4 + 0) * 256 + lane * 4) = x0 + y0;
+                *reinterpret_cast<f32x4 *>(Q + (2 * 4 + 1) * 256 + lane * 4) = x1 + y1;
+            }
+            W12_T1(h);
+            lds_barrier();
+        }
+        W12_LOOP_END;
+    } else {
+        // =========================================================================== tail (wave 11)
+        __builtin_amdgcn_s_setprio(3);
+        float ax[kAextra];
+#pragma unroll
+        for (int i = 0; i < kAextra; ++i) ax[i] = t.a_extra[(0 * kAextra + i) * 64 + lane];
+        const int lane_off = lo * t.n_cep + 4 * q;
+        Cursor ta = cursor_of(s, g, va), tb = cursor_of(s, g, vb);
+        lds_barrier();
+        W12_LOOP_BEGIN
+        for (int h = 0; h <= last_h; ++h) {
+            W12_T0
+            // the group that was in pass 2 at h - 1: A (tile h / 2 - 1) for even h, B (tile (h - 3) / 2) for odd h
+            const int gi = (h & 1) ? 1 : 0;
+            const int k = (h & 1) ? (h - 3) / 2 : h / 2 - 1;
+            if (h >= 2 && k >= 0 && k < (gi ? nB : nA)) {
+                const f32x4 *Q4 = reinterpret_cast<const f32x4 *>(Qt(gi)) + lane;
+                const f32x4 m0 = ((Q4[0 * 64] + Q4[2 * 64]) + (Q4[4 * 64] + Q4[6 * 64])) + Q4[8 * 64];
+                const f32x4 m1 = ((Q4[1 * 64] + Q4[3 * 64]) + (Q4[5 * 64] + Q4[7 * 64])) + Q4[9 * 64];
+                f32x4 l0, l1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    l0[r] = __builtin_amdgcn_logf(m0[r]);
+                    l1[r] = __builtin_amdgcn_logf(m1[r]);
+                }
+                if (t.n_mel <= 16) l1 = zero;          // no filters 16..31 (uniform)
+                f32x4 d0 = zero, d1 = zero;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d0 = MFCC_MFMA(ax[r], l0[r], d0);
+                    d1 = MFCC_MFMA(ax[4 + r], l1[r], d1);
+                }
+                Cursor &c = gi ? tb : ta;
+                dct_store(s, t, l0, l1, d0, d1, ax, c, lo, q, lane_off, out);
+                advance(c, g);
+            }
+            W12_T1(h);
+            lds_barrier();
+        }
+        W12_LOOP_END;
+    }
+}
+
+inline const char *kernel_name() { return "mfcc_fused512_w12_kernel"; }
+
+// returns false when the problem does not fit (then the 4-wave kernel runs)
+inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense, float *out, int n_cu,
+                   hipStream_t stream) {
+    if (t.win_dc != nullptr) return false;               // the double-precision DC path lives in the 4-wave kernel
+    const long long tiles_per_ch = (s.frames_per_ch + kTile - 1) / kTile;
+    const long long n_ch = s.total_frames / s.frames_per_ch;
+    const long long n_tiles = tiles_per_ch * n_ch;
+    if (n_tiles >= (1ll << 30) || tiles_per_ch >= (1ll << 26) || n_ch >= (1ll << 30)) return false;
+    long long wgs = (n_tiles + 1) / 2;
+    if (wgs > n_cu) wgs = n_cu;
+    if (wgs < 1) wgs = 1;
+    const long long grid = 2 * wgs;                      // virtual workgroups: the cursor stride
+    LaunchGeom g;
+    g.tiles_per_ch = (int)tiles_per_ch;
+    g.n_ch = (int)n_ch;
+    g.grid_div = (int)(grid / tiles_per_ch);
+    g.grid_mod = (int)(grid % tiles_per_ch);
+    g.step_ptr = (long long)g.grid_div * s.ch_stride + (long long)g.grid_mod * kTileHop;
+    g.wrap_ptr = s.ch_stride - tiles_per_ch * (long long)kTileHop;
+    g.t_lo = (int)((9 - (long long)s.halo + kTileHop - 1) / kTileHop);
+    if (g.t_lo < 0) g.t_lo = 0;
+    const long long hi = (s.n_samples - kSUsed) / kTileHop;
+    g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
+    if (dense)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, out);
+    else
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, out);
+    return true;
+}
+
+}  // namespace mfcc_fused12

@@ -18,6 +18,7 @@
 #include "kernel_fixed512.hpp"
 #include "kernel_fused1024.hpp"
 #include "kernel_fused512.hpp"
+#include "kernel_fused512_w12.hpp"
 #include "tables.hpp"
 
 namespace {
@@ -113,6 +114,7 @@ struct mfcc_hip_handle {
     bool fixed_ok = false;
     bool fused_ok = false;
     bool fused_dense = false;     // the fused kernel's banded MFMA list does not fit this sample rate: all pairs
+    bool fused_w12 = false;       // the twelve-wave form of the fused 512 kernel runs (kernel_fused512_w12.hpp)
     bool fused1k_ok = false;      // the fused 1024/341/40 float kernel covers this handle's parameters
     bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
@@ -338,6 +340,11 @@ int build_tables(mfcc_hip_handle *h) {
         h->xt.n_cep = r.n_cep;
     }
     if (h->fused_ok) mfcc_fused::bind_tables(b + o_fu, r.n_cep, r.n_mel, h->fused_dense, fused_dcx, h->fu);
+    {
+        // diagnostic override for A/B runs: MFCC_HIP_FUSED512=w4 keeps the four-wave form
+        const char *e = std::getenv("MFCC_HIP_FUSED512");
+        h->fused_w12 = h->fused_ok && !fused_dcx && !(e && std::strcmp(e, "w4") == 0);
+    }
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
@@ -407,7 +414,9 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
                 return MFCC_HIP_ERROR_UNSUPPORTED;
         }
     } else if (use_fused(h)) {
-        if (!mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
+        const bool done = h->fused_w12 &&
+                          mfcc_fused12::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream);
+        if (!done && !mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
     } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
                mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) {
@@ -952,7 +961,7 @@ int mfcc_hip_time_dev(mfcc_hip_handle *h, int fixed, const void *d_pcm, size_t n
 const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
-    if (use_fused(h)) return mfcc_fused::kernel_name();
+    if (use_fused(h)) return h->fused_w12 ? mfcc_fused12::kernel_name() : mfcc_fused::kernel_name();
     if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_fused1024::kernel_name();
     return "mfcc_float_generic_kernel";
 }
@@ -1282,6 +1291,16 @@ int mfcc_hip_eval_power(const int16_t *window, int n_cep, int n_frames, size_t h
     if (power_out) *power_out = power;
     return power >= 100000000ll ? 1 : 0;               // POWER_THRESHOLD, cepstrum.c:13
 }
+
+#ifdef MFCC_W12_STAMPS
+int mfcc_hip_debug_read_stamps12(unsigned long long *dst) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_fused12::g_stamps12), sizeof(unsigned long long) * 48) != hipSuccess)
+        return MFCC_HIP_ERROR_OTHER;
+    unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_fused12::g_stamps12), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
+    return MFCC_HIP_SUCCESS;
+}
+#endif
 
 #ifdef MFCC_FUSED_STAMPS
 // diagnostic build only: copy out and clear the per-phase cycle sums of the fused kernel

@@ -29,7 +29,7 @@ def mfcc_amd():
 def _both(mfcc_amd, x, sr, **kw):
     with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, **kw) as a, \
          mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, impl="generic", **kw) as b:
-        assert a.kernel_name().endswith("fused512_kernel") and b.kernel_name().endswith("generic_kernel")
+        assert a.kernel_name().startswith("mfcc_fused512") and b.kernel_name().endswith("generic_kernel")
         return a.process(x).astype(np.float64), b.process(x).astype(np.float64)
 
 

@@ -151,7 +151,7 @@ def test_fused_kernel_other_ncep_and_stream_padding(mfcc_amd, ncep):
     pcm = np.stack([mf.synth_pcm(170 * 50 + 512 + 37, seed=200 + s) for s in range(3)])
     ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream")
     with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=ncep, pad_mode="stream", impl="fused512") as m:
-        assert m.kernel_name().endswith("fused512_kernel")
+        assert m.kernel_name().startswith("mfcc_fused512")
         got = m.process(pcm)
     assert got.shape == ref.shape
     e_max, e_l2 = _err(got, ref)
@@ -263,7 +263,7 @@ def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
             got = m.process(x)
             if nfft == 512:
-                assert m.kernel_name().endswith("fused512_kernel")
+                assert m.kernel_name().startswith("mfcc_fused512")
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
@@ -276,7 +276,7 @@ def test_constructor_defaults_16_filters_run_on_the_fused_kernel(mfcc_amd, wav_p
     for ncep, pad in ((16, "notebook"), (5, "stream")):
         ref = mf.mfcc_float_ref(pcm, n_cep=ncep, n_mel=16, pad_mode=pad)
         with mfcc_amd.MFCC(nceptrums=ncep, pad_mode=pad) as m, mfcc_amd.MFCC(nceptrums=ncep, pad_mode=pad, impl="generic") as mg:
-            assert m.nfilters == 16 and m.kernel_name().endswith("fused512_kernel")
+            assert m.nfilters == 16 and m.kernel_name().startswith("mfcc_fused512")
             got = m.process(pcm)
             gen = mg.process(pcm)
         assert got.shape == ref.shape and np.isfinite(got).all()
