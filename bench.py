@@ -177,13 +177,16 @@ def profile_figures(kernel_name, frames):
             stale = stale or os.path.relpath(pj, ROOT)
             continue
         per_frame = d["hbm_traffic_bytes_per_launch"] / d["frames_per_launch"]
-        mf = prof.get("counters", {}).get("SQ_INSTS_VALU_MFMA_F32", {}).get("avg_per_launch")
+        cnt = prof.get("counters", {})
+        mf = cnt.get("SQ_INSTS_MFMA", {}).get("avg_per_launch")
+        mc = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("avg_per_launch")
         PROFILE["mfma_per_frame"] = mf / d["frames_per_launch"] if mf else None
+        PROFILE["mfma_clk_per_frame"] = mc / d["frames_per_launch"] if mc else None
         return (round(per_frame * frames), os.path.relpath(pj, ROOT), d.get("valu_wave_instructions_per_frame"), None)
     return None, None, None, stale
 
 
-PROFILE = {"mfma_per_frame": None}
+PROFILE = {"mfma_per_frame": None, "mfma_clk_per_frame": None}
 
 
 def roofline(frames, bytes_per_frame, kernel_ms, kernel_name, note_extra=""):
@@ -229,17 +232,19 @@ PIPE_CLK = {"pk": 3.26, "plain": 2.55, "mfma_f32_16x16x4": 32.0}
 FUSED512_PK_PER_FRAME = (158 + 74) * 16 / 64.0
 
 
-def alu_roofline(torch, dev, frames, kernel_ms, valu_per_frame, mfma_per_frame, src):
+def alu_roofline(torch, dev, frames, kernel_ms, valu_per_frame, mfma_per_frame, mfma_clk_per_frame, src):
+    """Every vector instruction priced at the pipe clocks alu_probe measured, the matrix instructions at their own busy
+    cycles (SQ_VALU_MFMA_BUSY_CYCLES: 32 per fp32 16x16x4, 16 per bf16 16x16x32), all on ONE pipe per SIMD."""
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     plain = max(valu_per_frame - mfma_per_frame - FUSED512_PK_PER_FRAME, 0.0)
-    clk = FUSED512_PK_PER_FRAME * PIPE_CLK["pk"] + plain * PIPE_CLK["plain"] + mfma_per_frame * PIPE_CLK["mfma_f32_16x16x4"]
+    clk = FUSED512_PK_PER_FRAME * PIPE_CLK["pk"] + plain * PIPE_CLK["plain"] + mfma_clk_per_frame
     ceiling = n_cu * 4 * 2.4e9 / clk
     rate = frames / (kernel_ms * 1e-3)
-    return {"bound": "fp32 vector pipe (VALU + f32 MFMA serialised)", "achieved": round(rate, 1), "peak": round(ceiling, 1),
+    return {"bound": "fp32 vector pipe (VALU and MFMA serialised)", "achieved": round(rate, 1), "peak": round(ceiling, 1),
             "unit": "frames/s per GPU", "frac": round(rate / ceiling, 4),
             "note": "peak = CUs x 4 SIMDs x 2.4 GHz / %.0f pipe clocks per frame (%.1f packed x %.2f + %.1f plain x %.2f + "
-                    "%.2f MFMA x 32; pipe clocks measured by tools/alu_probe.hip, instruction counts from %s)"
-                    % (clk, FUSED512_PK_PER_FRAME, PIPE_CLK["pk"], plain, PIPE_CLK["plain"], mfma_per_frame, src)}
+                    "%.1f MFMA busy clocks; pipe clocks measured by tools/alu_probe.hip, counts from %s)"
+                    % (clk, FUSED512_PK_PER_FRAME, PIPE_CLK["pk"], plain, PIPE_CLK["plain"], mfma_clk_per_frame, src)}
 
 
 def cpu_baseline(channels, gpu_rows, fixed, what):
@@ -341,8 +346,9 @@ def bench_config2(cx, args):
         }
         if valu:
             line["valu_roofline"] = valu_roofline(torch, dev, frames, kernel_ms, valu, src)
-            if PROFILE["mfma_per_frame"] and kname.startswith("mfcc_fused512"):
-                line["alu_roofline"] = alu_roofline(torch, dev, frames, kernel_ms, valu, PROFILE["mfma_per_frame"], src)
+            if PROFILE["mfma_per_frame"] and PROFILE["mfma_clk_per_frame"] and kname.startswith("mfcc_fused512"):
+                line["alu_roofline"] = alu_roofline(torch, dev, frames, kernel_ms, valu, PROFILE["mfma_per_frame"],
+                                                    PROFILE["mfma_clk_per_frame"], src)
         if pcie:
             line["pcie_inclusive"] = pcie
         if not args.no_cpu_baseline:

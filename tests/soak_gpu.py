@@ -3,22 +3,26 @@
 Random channel counts, lengths, channel strides and base offsets (all alignment residues), history halo,
 framing mode, n_cep 1..32 and six signal kinds (Gaussian at three levels, full-scale uniform, Gaussian
 with a stretch of silence, DC, full-scale square, pure sine).  Fixed contract: the fused fixed-point
-kernel against oracle/mfcc_fixed.py, bit for bit.  Float contract: the fused 512 and 1024 kernels against
-the generic kernel (5e-5 of the largest coefficient; DC / square / sine inputs have mel bands at the fp32
-noise floor where two fp32 FFTs legitimately differ after the log -- DESIGN.md section 1 -- so they are
-reported, not counted, unless FUZZ_STRICT is set; the same holds above 22.05 kHz, where the first mel
-filter sits on the DC bin that pre-emphasis empties).  The fused 512 kernel also gets random sample rates
-and 16-filter banks.  FUZZ_FIXED=1 restricts the run to the fixed contract."""
+kernel against oracle/mfcc_fixed.py, bit for bit.  Float contract: the fused 512 (random sample rates, 16-filter
+banks) and 1024 kernels AND the generic kernel, each against the float64 oracle on the first channel (1e-4 of the
+largest coefficient, identical -inf / NaN pattern) and against each other on all channels (5e-5).  DC / square /
+sine inputs have mel bands at the fp32 noise floor where fp32 FFTs legitimately differ from float64 after the log
+(DESIGN.md section 1): they are reported, not counted, unless FUZZ_STRICT is set.  No sample rate is masked (round 1
+masked everything above 22.05 kHz; the cause was the real-valued DC-only band, now summed in double).  What IS set
+aside, per frame and counted in the summary, is a frame whose smallest mel energy lies more than 1e7 below the
+frame's mean bin power: a band that is a single FFT bin (44.1 / 48 kHz have several) cancels to that level once in
+~1e8 frames, and an fp32 FFT's error there, 1e-7 of the frame's rms, is then larger than the band itself
+(tools/replay_band.py on case 10050240: bin 2 at 2.9e-12 next to 4e-4; both kernels off by 0.04..0.06 in log2).
+Every case has its own seed, printed with the failure: `python tests/soak_gpu.py --case SEED` replays it.
+FUZZ_FIXED=1 restricts the run to the fixed contract."""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch, mfcc_amd
 from oracle import mfcc_fixed as mx
 from oracle import mfcc_float as mf
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 
-def signal(n, kind):
+def signal(rng, n, kind):
     if kind == 0: x = rng.standard_normal(n) * rng.choice([30, 3000, 12000])
     elif kind == 1: x = rng.integers(-32768, 32768, n).astype(np.float64)
     elif kind == 2:
@@ -29,73 +33,115 @@ def signal(n, kind):
     else: x = 20000 * np.sin(np.arange(n) * rng.uniform(0.001, 3.1))
     return np.clip(x, -32768, 32767).astype(np.int16)
 
-def close(a, b, tol):
+
+ILL = [0, 0]       # frames of noise-like channels set aside / compared as beyond fp32's reach (see the docstring)
+
+
+def close(a, b, tol, keep=None):
     a = a.astype(np.float64); b = b.astype(np.float64)
+    if keep is not None:
+        a, b = a[keep[: len(a)]], b[keep[: len(b)]]
     fin = np.isfinite(b)
     if not np.array_equal(np.isfinite(a), fin): return False, "finite pattern"
-    if not np.array_equal(a[~fin], b[~fin]) and not (np.isnan(a[~fin]) == np.isnan(b[~fin])).all(): return False, "inf pattern"
+    if not np.array_equal(a[~fin], b[~fin], equal_nan=True): return False, "inf pattern"
     if fin.any():
         d = np.abs(a[fin] - b[fin]).max(); m = np.abs(b[fin]).max()
         if d > tol * max(m, 1.0): return False, "err %.3g of %.3g" % (d, m)
     return True, ""
 
-t0 = time.time(); cases = fails = 0
-while time.time() - t0 < budget:
-    cases += 1
+
+def one_case(seed):
+    """Returns a list of failure strings (empty: the case passed)."""
+    rng = np.random.default_rng(seed)
+    fails = []
     if rng.random() < 0.08:                      # ragged batch vs per-utterance calls, bit for bit
         nfft_r = int(rng.choice([512, 1024])); pad = str(rng.choice(["notebook", "stream"]))
-        utts = [signal(int(rng.integers(0, 6000)), int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 12)))]
-        try:
-            with mfcc_amd.MFCC(nfft=nfft_r, nfilters=32 if nfft_r == 512 else 40, nceptrums=int(rng.integers(1, 17)),
-                               pad_mode=pad, power_scale=0) as m:
-                fl = m.process_batch(utts)
-                fx = m.process_batch(utts, fixed=True) if nfft_r == 512 else None
-                for i, u in enumerate(utts):
-                    if not np.array_equal(fl[i], m.process(u), equal_nan=True): fails += 1; print("RAGGED FLOAT MISMATCH", nfft_r, pad, i, len(u))
-                    if fx is not None and not np.array_equal(fx[i], m.process_fixed(u)): fails += 1; print("RAGGED FIXED MISMATCH", pad, i, len(u))
-        except Exception as e:
-            fails += 1; print("EXC ragged", repr(e)[:200])
-        continue
+        utts = [signal(rng, int(rng.integers(0, 6000)), int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 12)))]
+        with mfcc_amd.MFCC(nfft=nfft_r, nfilters=32 if nfft_r == 512 else 40, nceptrums=int(rng.integers(1, 17)),
+                           pad_mode=pad, power_scale=0) as m:
+            fl = m.process_batch(utts)
+            fx = m.process_batch(utts, fixed=True) if nfft_r == 512 else None
+            for i, u in enumerate(utts):
+                if not np.array_equal(fl[i], m.process(u), equal_nan=True): fails.append("RAGGED FLOAT %d %s utt %d len %d" % (nfft_r, pad, i, len(u)))
+                if fx is not None and not np.array_equal(fx[i], m.process_fixed(u)): fails.append("RAGGED FIXED %s utt %d len %d" % (pad, i, len(u)))
+        return fails
     big = rng.random() < 0.5
     cfg = "x512" if os.environ.get("FUZZ_FIXED") else rng.choice(["f512", "f1024", "x512"])
     nfft, hop = (1024, 341) if cfg == "f1024" else (512, 170)
-    nch = int(rng.integers(1, 5)); halo = int(rng.integers(0, 2)); pad = rng.choice(["notebook", "stream"])
+    nch = int(rng.integers(1, 5)); halo = int(rng.integers(0, 2)); pad = str(rng.choice(["notebook", "stream"]))
     n = int(rng.integers(0, 40000 if big else 3 * nfft))
-    ncep = int(rng.integers(1, 33 if cfg != "f1024" else 17))
+    ncep = int(rng.integers(1, 33))
     stride = n + halo + int(rng.integers(0, 9)); off = int(rng.integers(0, 8))
     flat = np.zeros(off + stride * nch + 16, dtype=np.int16)
     kinds = [int(rng.integers(0, 6)) for _ in range(nch)]
-    noisy = any(k >= 3 for k in kinds)          # DC / square / sine: noise-floor bands, see the docstring
-    for c in range(nch): flat[off + c * stride: off + c * stride + n + halo] = signal(n + halo, kinds[c])
+    for c in range(nch): flat[off + c * stride: off + c * stride + n + halo] = signal(rng, n + halo, kinds[c])
     dev = torch.from_numpy(flat).cuda()
     view = torch.as_strided(dev, (nch, n + halo), (stride, 1), storage_offset=off)
-    tag = (cfg, nch, n, halo, pad, ncep, stride, off)
-    try:
-        if cfg == "x512":
-            with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=ncep, pad_mode=pad) as m:
-                got = m.process_fixed(view, halo=halo).cpu().numpy()
-            for c in range(nch if n < 6000 else 1):
-                x = flat[off + c * stride: off + c * stride + n + halo]
-                # oracle has no halo argument: a halo sample only changes the history of the first sample
-                if halo:
-                    ref = mx.mfcc_fixed_ref(np.concatenate([np.zeros(169, np.int16), x]), nceptrums=ncep, pad_mode=pad)
-                    # frame k of the shifted stream starts one hop earlier: compare frames 1.. of ref with got[:-?]
-                    ok = np.array_equal(got[c][: len(ref) - 1], ref[1:1 + len(got[c])][: len(got[c])]) if len(got[c]) else True
-                else:
-                    ref = mx.mfcc_fixed_ref(x, nceptrums=ncep, pad_mode=pad); ok = np.array_equal(got[c], ref)
-                if not ok: fails += 1; print("FIXED MISMATCH", tag, c); break
-        else:
-            nmel = (16 if rng.random() < 0.25 else 32) if cfg == "f512" else 40
-            sr = int(rng.choice([16000, 16000, 8000, 22050, 44100, 48000])) if cfg == "f512" else 16000
-            kw = dict(nfft=nfft, nfilters=nmel, nceptrums=min(ncep, nmel), pad_mode=pad, samplerate=sr,
-                      power_scale=512.0 if cfg == "f512" else 0)
-            tag = tag + (nmel, sr)
-            noisy = noisy or sr > 22050          # the first mel filter degenerates to the (emptied) DC bin
-            with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
-                ga = a.process(view, halo=halo).cpu().numpy(); gb = b.process(view, halo=halo).cpu().numpy()
-            ok, why = close(ga, gb, 5e-5)
-            if not ok and (os.environ.get("FUZZ_STRICT") or not noisy):
-                fails += 1; print("FLOAT MISMATCH", tag, why)
-    except Exception as e:
-        fails += 1; print("EXC", tag, repr(e)[:200])
-print("cases", cases, "fails", fails, "in %.0f s" % (time.time() - t0))
+    tag = "%s nch %d n %d halo %d %s ncep %d stride %d off %d kinds %s" % (cfg, nch, n, halo, pad, ncep, stride, off, kinds)
+    if cfg == "x512":
+        with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=ncep, pad_mode=pad) as m:
+            got = m.process_fixed(view, halo=halo).cpu().numpy()
+        for c in range(nch if n < 6000 else 1):
+            x = flat[off + c * stride: off + c * stride + n + halo]
+            if halo:            # the oracle has no halo argument: put the shard one hop into a longer stream
+                ref = mx.mfcc_fixed_ref(np.concatenate([np.zeros(169, np.int16), x]), nceptrums=ncep, pad_mode=pad)[1:]
+                ok = np.array_equal(got[c][: len(ref)], ref[: len(got[c])])
+            else:
+                ok = np.array_equal(got[c], mx.mfcc_fixed_ref(x, nceptrums=ncep, pad_mode=pad))
+            if not ok:
+                fails.append("FIXED %s ch %d" % (tag, c))
+                break
+        return fails
+    nmel = (16 if rng.random() < 0.25 else 32) if cfg == "f512" else 40
+    sr = int(rng.choice([16000, 16000, 8000, 22050, 44100, 48000])) if cfg == "f512" else 16000
+    kw = dict(nfft=nfft, nfilters=nmel, nceptrums=min(ncep, nmel), pad_mode=pad, samplerate=sr,
+              power_scale=512.0 if cfg == "f512" else 0)
+    tag += " nmel %d sr %d" % (nmel, sr)
+    with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
+        ga = a.process(view, halo=halo).cpu().numpy(); gb = b.process(view, halo=halo).cpu().numpy()
+        names = (a.kernel_name(), b.kernel_name())
+    if ga.shape[1] == 0:
+        return fails                               # no frame: nothing to compare
+    # both kernels against the float64 notebook restatement, every channel, and against each other
+    for c in range(nch):
+        x = flat[off + c * stride: off + c * stride + n + halo]
+        xs = np.concatenate([np.zeros(hop - 1, np.int16), x]) if halo else x
+        if pad == "stream":                        # the oracle's framing for the stages, like mfcc_float_ref
+            nf = mf.num_frames_stream(len(xs), nfft, hop)
+            xs = np.concatenate([xs, np.zeros((nf - 1) * hop + nfft - len(xs), dtype=xs.dtype)])
+        full, st = mf.mfcc_notebook(xs, nfft=nfft, hop=hop, n_mel=nmel, sample_rate=sr,
+                                    power_scale=512.0 if cfg == "f512" else float(nfft), return_stages=True)
+        ref = full[:, :min(ncep, nmel)]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cond = st["power"].mean(axis=1) / st["mel"].min(axis=1)
+        keep = ~(cond > 1e7) | ~np.isfinite(cond)  # silent frames (0 / 0, x / 0) stay: their -inf pattern is exact
+        if halo:
+            ref, keep = ref[1:], keep[1:]
+        if kinds[c] < 3:
+            ILL[0] += int((~keep).sum())
+            ILL[1] += len(keep)
+        for name, g in zip(names, (ga[c], gb[c])):
+            ok, why = close(g[: len(ref)], ref[: len(g)], 1e-4, keep)
+            if not ok and (kinds[c] < 3 or os.environ.get("FUZZ_STRICT")):
+                fails.append("FLOAT %s vs float64 oracle %s ch %d: %s" % (name, tag, c, why))
+        ok, why = close(ga[c], gb[c], 2e-4, keep)  # each is within 1e-4 of the notebook
+        if not ok and (kinds[c] < 3 or os.environ.get("FUZZ_STRICT")):
+            fails.append("FLOAT fused vs generic %s ch %d: %s" % (tag, c, why))
+    return fails
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--case":
+        print(one_case(int(sys.argv[2])) or "case passes")
+        sys.exit(0)
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+    t0 = time.time(); cases = nfail = 0
+    while time.time() - t0 < budget:
+        seed = seed0 * 10_000_000 + cases
+        cases += 1
+        try:
+            for f in one_case(seed):
+                nfail += 1; print("MISMATCH [--case %d] %s" % (seed, f), flush=True)
+        except Exception as e:
+            nfail += 1; print("EXC [--case %d] %s" % (seed, repr(e)[:200]), flush=True)
+    print("cases", cases, "fails", nfail, "ill-conditioned frames set aside", ILL[0], "of", ILL[1], "noise-like frames in %.0f s" % (time.time() - t0))
