@@ -20,8 +20,12 @@
 // Time runs in HALF-STEPS h = 0, 1, 2, ... separated by ONE workgroup barrier each:
 //   group A: pass 1 of its tile k at h = 2 k,     pass 2 + mel at h = 2 k + 1
 //   group B: pass 1 of its tile k at h = 2 k + 1, pass 2 + mel at h = 2 k + 2
-//   parkers: at h they park the window fetched during h - 1: S_B(h / 2) for even h, S_A((h + 1) / 2) for odd h
-//            (a group's window is rewritten while that group is in pass 2 and nobody reads it)
+//   Pass 1 runs on operands the wave read out of its group's sample window one half-step EARLIER, in the middle of
+//   its own pass 2 of the previous tile (between the power split and the MFMAs): the half-step then starts on
+//   registers instead of on 32 LDS reads, while the partner group reads its T columns.
+//   parkers: at h they park the window fetched during h - 2: S_A(h / 2 + 1) for even h, S_B((h + 1) / 2) for odd h
+//            (a group's window is rewritten while that group runs pass 1 out of registers; it reads it in its next
+//            pass 2); HBM latency under load is longer than a half-step, hence the two half-steps of lead
 //   column 16 at h: the group in pass 2 (its V was written in h - 1); its partial sums go to Q slot 4 of the group
 //   tail at h: the group that was in pass 2 at h - 1 (Q complete at the barrier; rewritten only at h + 1)
 // LDS (114.5 KB): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
@@ -157,58 +161,78 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         const int n_mine = gi ? nB : nA;
         Cursor cur = cursor_of(s, g, gi ? vb : va);
 
-        lds_barrier();                                 // the parkers' prologue: S_A(0) is in LDS
-        W12_LOOP_BEGIN
-        for (int h = 0; h <= last_h; ++h) {
-            W12_T0
-            const int rel = h - gi;                    // >= 0: pass 1 of tile rel / 2 (rel even), pass 2 of (rel - 1) / 2 (odd)
-            if (rel >= 0 && !(rel & 1) && (rel >> 1) < n_mine) {
-                // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
-                // (the longer of the two phases: it gets the SIMD's issue priority over the partner group's pass 2,
-                // whichever of the two waves is older -- measured: 2000 clocks per half-step instead of 2400)
-                __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P1);
-                const int shift = window_of(cur, g).shift;
-                v2f ep[16];
-                {
-                    const float *sp = S + lane_slot + shift;
+        lds_barrier();                                 // the parkers' prologue: S_A(0) and S_B(0) are in LDS
+        // The pass-1 operands of a tile are read out of its window ONE half-step early, in the middle of the same
+        // group's pass 2 of the previous tile (the window was re-parked the half-step before that): pass 1 then starts
+        // on registers instead of waiting for 32 LDS reads while the partner group does the same for its T columns.
+        v2f ep[16];
+        auto load_ep = [&]() {
+            const float *sp = S + lane_slot + window_of(cur, g).shift;
 #pragma unroll
-                    for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
-                }
-                v2f ty[16];
-                float y16;
-                mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
-                v2f *trow = reinterpret_cast<v2f *>(T + fr_id * kTFrame + lo * kTRow);
+            for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
+        };
+        if (n_mine > 0) load_ep();                     // tile 0 (group B idles through h = 0 with its operands loaded)
+        lds_barrier();                                 // second prologue barrier: the parkers may now re-park S_A (h = 0)
+        auto pass1 = [&]() {
+            // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
+            // (the longer of the two phases: it gets the SIMD's issue priority over the partner group's pass 2,
+            // whichever of the two waves is older -- measured: 2000 clocks per half-step instead of 2400)
+            __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P1);
+            v2f ty[16];
+            float y16;
+            mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
+            v2f *trow = reinterpret_cast<v2f *>(T + fr_id * kTFrame + lo * kTRow);
 #pragma unroll
-                for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
-                V[fr_id * kVStride + lo] = y16;
-            } else if (rel >= 1 && (rel & 1) && ((rel - 1) >> 1) < n_mine) {
-                // ---------------- pass 2: complex FFT-16 over n2 for frame lo, column k1 = 4 wi + q; mel MFMAs
-                __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P2);
-                float pw[16];
-                {
-                    v2f x[16], z[16];
-                    const v2f *tcol = reinterpret_cast<const v2f *>(T + lo * kTFrame + 2 * (4 * wi + q));
+            for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
+            V[fr_id * kVStride + lo] = y16;
+        };
+        auto pass2 = [&]() {
+            // ---------------- pass 2: complex FFT-16 over n2 for frame lo, column k1 = 4 wi + q; mel MFMAs
+            __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P2);
+            float pw[16];
+            {
+                v2f x[16], z[16];
+                const v2f *tcol = reinterpret_cast<const v2f *>(T + lo * kTFrame + 2 * (4 * wi + q));
 #pragma unroll
-                    for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
-                    mfcc_codelets::cfft16(x, z);
+                for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
+                mfcc_codelets::cfft16(x, z);
 #pragma unroll
-                    for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
-                }
-                PowerBf pb;
-                split_power(pw, pb);
-                f32x4 acc[kSets];
-#pragma unroll
-                for (int st = 0; st < kSets; ++st) acc[st] = zero;
-                mel_bf_all<DENSE, 0>(ah, al, pb, acc, [](auto) {});
-                f32x4 b0, b1;
-                mel_bf_blocks<DENSE>(acc, b0, b1);
-                *reinterpret_cast<f32x4 *>(Q + (2 * wi + 0) * 256 + lane * 4) = b0;
-                *reinterpret_cast<f32x4 *>(Q + (2 * wi + 1) * 256 + lane * 4) = b1;
-                advance(cur, g);
+                for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
             }
-            W12_T1(h);
+            PowerBf pb;
+            split_power(pw, pb);
+            advance(cur, g);
+            load_ep();           // the next tile's operands fly during the MFMAs (after the last tile they are never used)
+            f32x4 acc[kSets];
+#pragma unroll
+            for (int st = 0; st < kSets; ++st) acc[st] = zero;
+            mel_bf_all<DENSE, 0>(ah, al, pb, acc, [](auto) {});
+            f32x4 b0, b1;
+            mel_bf_blocks<DENSE>(acc, b0, b1);
+            *reinterpret_cast<f32x4 *>(Q + (2 * wi + 0) * 256 + lane * 4) = b0;
+            *reinterpret_cast<f32x4 *>(Q + (2 * wi + 1) * 256 + lane * 4) = b1;
+        };
+        // pass 1 and pass 2 of a tile are consecutive half-steps for either group (B one half-step behind A): an
+        // unconditional loop body, so that `ep` -- defined at the end of pass 2, consumed by the next pass 1 -- is not
+        // live through pass 2's register peak; the half-steps in which the group has nothing to do are bare barriers
+        W12_LOOP_BEGIN
+        int bars = last_h + 1;                         // every wave of the workgroup passes this many barriers
+        if (gi) {                                      // h = 0: group B idles
             lds_barrier();
+            --bars;
         }
+        for (int i = 0; i < n_mine; ++i) {
+            W12_T0
+            pass1();
+            W12_T1(0);
+            lds_barrier();
+            W12_T0
+            pass2();
+            W12_T1(1);
+            lds_barrier();
+            bars -= 2;
+        }
+        for (; bars > 0; --bars) lds_barrier();
         W12_LOOP_END;
     } else if (wi < 2) {
         // =========================================================================== parkers (waves 8, 9)
@@ -222,29 +246,38 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         // load is longer than a half-step), i.e. right after the same stream's previous window has been parked
         Fetch3 fa, fb;
         bool have_a = false, have_b = false;
-        if (nA > 0) {                                  // prologue: S_A(0) directly
+        if (nA > 0) {                                  // prologue: S_A(0) and S_B(0) directly
             fetch_window3(s, window_of(pa, g), u, fa);
             park_window3(Sf(0), u, fa);
             advance(pa, g);
             ++ka;
         }
-        if (nB > 0) {                                  // S_B(0): parked at h = 0
+        if (nB > 0) {
             fetch_window3(s, window_of(pb, g), u, fb);
+            park_window3(Sf(1), u, fb);
             advance(pb, g);
             ++kb;
-            have_b = true;
         }
-        if (ka < nA) {                                 // S_A(1): parked at h = 1
+        if (ka < nA) {                                 // S_A(1): parked at h = 0
             fetch_window3(s, window_of(pa, g), u, fa);
             advance(pa, g);
             ++ka;
             have_a = true;
         }
-        lds_barrier();                                 // S_A(0) is parked: h = 0 may start
+        if (kb < nB) {                                 // S_B(1): parked at h = 1
+            fetch_window3(s, window_of(pb, g), u, fb);
+            advance(pb, g);
+            ++kb;
+            have_b = true;
+        }
+        lds_barrier();                                 // S_A(0), S_B(0) are parked: the workers fetch tile 0's operands
+        lds_barrier();                                 // ... and hold them in registers: h = 0 may start
         W12_LOOP_BEGIN
         for (int h = 0; h <= last_h; ++h) {
             W12_T0
-            if (h & 1) {                               // odd h: S_A((h + 1) / 2), then fetch S_A((h + 3) / 2) for h + 2
+            // A window is re-parked in the half-step in which its group runs pass 1 on operands it already holds in
+            // registers: S_A(h / 2 + 1) at even h, S_B((h + 1) / 2) at odd h; the group reads it in its next pass 2
+            if (!(h & 1)) {
                 if (have_a) park_window3(Sf(0), u, fa);
                 have_a = false;
                 if (ka < nA) {
@@ -253,7 +286,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     ++ka;
                     have_a = true;
                 }
-            } else {                                   // even h: S_B(h / 2), then fetch S_B(h / 2 + 1) for h + 2
+            } else {
                 if (have_b) park_window3(Sf(1), u, fb);
                 have_b = false;
                 if (kb < nB) {
@@ -273,7 +306,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         float ax[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ax[i] = t.a_extra[(1 * kAextra + i) * 64 + lane];
-        lds_barrier();                                 // matches the parkers' prologue barrier
+        lds_barrier();                                 // the parkers' two prologue barriers
+        lds_barrier();
         W12_LOOP_BEGIN
         for (int h = 0; h <= last_h; ++h) {
             W12_T0
@@ -309,6 +343,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         for (int i = 0; i < kAextra; ++i) ax[i] = t.a_extra[(0 * kAextra + i) * 64 + lane];
         const int lane_off = lo * t.n_cep + 4 * q;
         Cursor ta = cursor_of(s, g, va), tb = cursor_of(s, g, vb);
+        lds_barrier();
         lds_barrier();
         W12_LOOP_BEGIN
         for (int h = 0; h <= last_h; ++h) {

@@ -182,3 +182,61 @@ void mfcc_close(struct mfcc_s *sess) { mfcc_hip_destroy(sess->h); }
 """)
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                     str(src)], check=True)
+
+
+def test_lift_file_is_lift_py_on_a_file(tmp_path):
+    """`.mfcc` -> `.lift` (software/lift.py:28-40), host only: lifter L = 22 in double, then `astype(np.int16)` --
+    truncation toward zero, low 16 bits beyond int16 (full-range input makes n = 11's factor 12 overflow)."""
+    rng = np.random.default_rng(3)
+    cep = rng.integers(-32768, 32768, (70, 32)).astype(np.int16)
+    cep[0, :] = 32767
+    cep[1, :] = -32768
+    src, dst = tmp_path / "x.mfcc", tmp_path / "x.lift"
+    cep.tofile(src)
+    assert mfcc_amd.lift_file(src, dst, nceptrums=32, L=22) == 70
+    with np.errstate(invalid="ignore"):
+        want = mf.lifter(cep, 22).astype(np.int16)                       # what lift.py writes
+    assert np.array_equal(np.fromfile(dst, dtype=np.int16).reshape(-1, 32), want)
+    # L <= 0: unchanged; a file that is not a whole number of rows is refused like np.reshape would
+    assert mfcc_amd.lift_file(src, dst, nceptrums=32, L=0) == 70
+    assert np.array_equal(np.fromfile(dst, dtype=np.int16).reshape(-1, 32), cep)
+    cep.reshape(-1)[:-5].tofile(src)
+    with pytest.raises(mfcc_amd.MfccHipError) as e:
+        mfcc_amd.lift_file(src, dst, nceptrums=32)
+    assert e.value.code == -101
+    with pytest.raises(mfcc_amd.MfccHipError) as e:
+        mfcc_amd.lift_file(tmp_path / "missing.mfcc", dst)
+    assert e.value.code == -107
+
+
+def test_stream_entry_points_check_their_arguments_without_a_gpu():
+    import ctypes as C
+    lib = mfcc_amd.load_library()
+    s = C.c_void_p()
+    assert lib.mfcc_hip_stream_create(None, 0, C.byref(s)) == -101 and not s.value
+    assert lib.mfcc_hip_stream_push(None, None, 0, None, 0, None) == -101
+    assert lib.mfcc_hip_stream_flush(None, None, 0, None) == -101
+    assert lib.mfcc_hip_stream_reset(None) == -101
+    assert lib.mfcc_hip_stream_pending(None) == 0 and lib.mfcc_hip_stream_max_frames(None, 100) == 0
+    lib.mfcc_hip_stream_destroy(None)
+    assert lib.mfcc_hip_abi_version() == 2
+
+
+def test_fixed_support_follows_the_rtl_filterbank():
+    """The fixed path exists where the RTL's streaming filterbank emits n_mel values per frame (the oracle asserts
+    on exactly the other sets)."""
+    from mfcc_amd import _lib
+    for nfft, nmel, ok in ((512, 32, True), (256, 16, True), (1024, 64, True), (128, 16, True), (64, 8, True),
+                           (256, 64, False), (512, 64, False), (128, 32, False), (64, 16, False)):
+        try:
+            mfcc_amd.get_table(_lib.TABLE_FX_MEL_DENSE_U32, nfft=nfft, nfilters=nmel, nceptrums=4)
+            got = True
+        except mfcc_amd.MfccHipError as e:
+            assert e.code == -105
+            got = False
+        assert got == ok, (nfft, nmel)
+        if ok:
+            mx.mfcc_fixed_ref(np.zeros(nfft * 2, np.int16), nfft=nfft, nfilters=nmel, nceptrums=4)
+        else:
+            with pytest.raises(AssertionError):
+                mx.mfcc_fixed_ref(np.zeros(nfft * 2, np.int16), nfft=nfft, nfilters=nmel, nceptrums=4)
