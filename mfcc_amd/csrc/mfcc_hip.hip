@@ -509,15 +509,31 @@ __global__ void gather_rows_kernel(const OutT *__restrict__ src, OutT *__restric
     }
 }
 
-// device-resident input: copy every utterance to its place in the packed stream
+// device-resident input: copy every utterance to its place in the packed stream and zero what lies between it and
+// the next one (no memset of the whole stream: every sample of it is written exactly once).  16 bytes per lane:
+// the destination is brought to 16-byte alignment first, the source is read as it lies (2-byte aligned; global
+// memory takes unaligned vector loads)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(2))) Unaligned16 {
+    u32x4_t v;
+};
+
 __global__ void pack_utterances_kernel(const int16_t *__restrict__ src, int16_t *__restrict__ dst,
                                        const long long *__restrict__ desc, long long n_utt) {
-    // desc: (source offset, destination offset, samples) per utterance
+    // desc: (source offset, destination offset, samples, end of this utterance's part of the stream) per utterance
     for (long long u = blockIdx.x; u < n_utt; u += gridDim.x) {
-        const int16_t *s0 = src + desc[3 * u];
-        int16_t *d0 = dst + desc[3 * u + 1];
-        const long long n = desc[3 * u + 2];
-        for (long long i = threadIdx.x; i < n; i += blockDim.x) d0[i] = s0[i];
+        const long long n = desc[4 * u + 2], span = desc[4 * u + 3] - desc[4 * u + 1];
+        if (span <= 0) continue;
+        const int16_t *s0 = src + desc[4 * u];
+        int16_t *d0 = dst + desc[4 * u + 1];
+        long long head = (long long)(((16 - (reinterpret_cast<uintptr_t>(d0) & 15)) & 15) >> 1);
+        if (head > n) head = n;
+        for (long long i = threadIdx.x; i < head; i += blockDim.x) d0[i] = s0[i];
+        const long long nvec = (n - head) >> 3;
+        u32x4_t *dv = reinterpret_cast<u32x4_t *>(d0 + head);
+        const Unaligned16 *sv = reinterpret_cast<const Unaligned16 *>(s0 + head);
+        for (long long v = threadIdx.x; v < nvec; v += blockDim.x) dv[v] = sv[v].v;
+        for (long long i = head + 8 * nvec + threadIdx.x; i < span; i += blockDim.x) d0[i] = i < n ? s0[i] : int16_t(0);
     }
 }
 
@@ -528,11 +544,12 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
     const size_t hop = size_t(h->r.hop), nfft = size_t(h->r.nfft), ncep = size_t(h->r.n_cep);
     DeviceGuard guard(h->device);
-    mfcc_hip_handle::PinnedDesc *pd = nullptr;     // [0, 3n): pack descriptors, [3n, 6n): row-gather descriptors, in
-    int rc = desc_acquire(h, 6 * n_utt, &pd);      // pinned memory: the H2D copy below is asynchronous
+    mfcc_hip_handle::PinnedDesc *pd = nullptr;     // [0, 4n): pack descriptors, [4n, 7n): row-gather descriptors, in
+    int rc = desc_acquire(h, 7 * n_utt, &pd);      // pinned memory: the H2D copy below is asynchronous
     if (rc) return rc;
     long long *desc = pd->p;
-    for (size_t i = 0; i < 6 * n_utt; ++i) desc[i] = 0;
+    for (size_t i = 0; i < 7 * n_utt; ++i) desc[i] = 0;
+    size_t last_with_frames = n_utt;
     size_t pos = 0, total = 0;
     frame_offsets[0] = 0;
     for (size_t u = 0; u < n_utt; ++u) {
@@ -540,18 +557,20 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
         const size_t n = offsets[u + 1] - offsets[u];
         if (n && !d_pcm) return MFCC_HIP_ERROR_INVALID_PARAM;
         const size_t nf = count_frames(h->r, n);
-        desc[3 * u] = (long long)offsets[u];
-        desc[3 * u + 1] = (long long)pos;
-        desc[3 * u + 2] = nf ? (long long)n : 0;
-        desc[3 * n_utt + 3 * u] = (long long)(pos / hop);
-        desc[3 * n_utt + 3 * u + 1] = (long long)total;
-        desc[3 * n_utt + 3 * u + 2] = (long long)nf;
+        desc[4 * u] = (long long)offsets[u];
+        desc[4 * u + 1] = (long long)pos;
+        desc[4 * u + 2] = nf ? (long long)n : 0;
+        desc[4 * n_utt + 3 * u] = (long long)(pos / hop);
+        desc[4 * n_utt + 3 * u + 1] = (long long)total;
+        desc[4 * n_utt + 3 * u + 2] = (long long)nf;
         total += nf;
         frame_offsets[u + 1] = total;
         if (nf) {
             const size_t extent = std::max(n, hop * (nf - 1) + nfft);
             pos = (pos + extent + 1 + hop - 1) / hop * hop;
+            last_with_frames = u;
         }
+        desc[4 * u + 3] = (long long)pos;          // this utterance's part of the stream ends where the next begins
     }
     if (total == 0) return MFCC_HIP_SUCCESS;
     if (!d_out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
@@ -566,7 +585,8 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
             return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
     }
     const size_t F = pos / hop, len = pos + nfft + hop;
-    const size_t desc_bytes = 6 * n_utt * sizeof(long long);
+    desc[4 * last_with_frames + 3] = (long long)len;     // the last one also zeroes the tail of the stream
+    const size_t desc_bytes = 7 * n_utt * sizeof(long long);
     rc = ensure(h, &h->d_in, &h->d_in_bytes, len * sizeof(int16_t) + 64);
     if (rc) return rc;
     rc = ensure(h, &h->d_out, &h->d_out_bytes, F * ncep * sizeof(OutT) + desc_bytes + 64);
@@ -575,7 +595,6 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     OutT *d_all = static_cast<OutT *>(h->d_out);
     const size_t desc_off = (F * ncep * sizeof(OutT) + 7) & ~size_t(7);
     long long *d_desc = reinterpret_cast<long long *>(static_cast<char *>(h->d_out) + desc_off);
-    HIP_TRY(h, hipMemsetAsync(h->d_in, 0, len * sizeof(int16_t), h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_desc, desc, desc_bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(pd->copied, h->stream));
     pd->in_flight = true;
@@ -585,7 +604,7 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     rc = launch(h, fixed, h->d_in, len, len, 1, 0, d_all, nullptr, F);
     if (rc) return rc;
     hipLaunchKernelGGL(gather_rows_kernel<OutT>, dim3(blocks), dim3(256), 0, h->stream, d_all, d_out,
-                       d_desc + 3 * n_utt, (long long)n_utt, (int)ncep);
+                       d_desc + 4 * n_utt, (long long)n_utt, (int)ncep);
     HIP_TRY(h, hipGetLastError());
     return scratch_release(h);
 }
