@@ -88,6 +88,76 @@ __device__ __forceinline__ Cursor cursor_of(const mfcc_k::StreamDesc &s, const L
     return c;
 }
 
+// ---- ragged corpora without a packing copy: the tiles of utterances of different lengths, straight out of the
+// caller's buffer.  Per utterance one record, per tile one (utterance, tile-in-utterance) pair; a wave fetches both with
+// scalar loads when it moves to its next tile.  Every utterance is an independent stream that starts from reset
+// (history 0) and is zero-padded at its end, exactly like a channel of the plain call -- so the frames are the same
+// bits as one call per utterance.
+struct RaggedChan {
+    long long pcm_off;       // first sample of the utterance, relative to StreamDesc::pcm
+    long long out_row;       // first output row (frame) of the utterance
+    int n_samples, frames;   // of the utterance
+    int t_hi;                // tiles 1 .. t_hi have their whole window inside the utterance
+    int tile0;               // index of its first tile in the tile map
+};
+struct RaggedTables {
+    const int2 *tile_map;    // [n_tiles] (utterance, tile in utterance)
+    const RaggedChan *chans; // [n_utterances]
+    int n_tiles;
+};
+
+// One role's walk over one group's tiles (virtual workgroup v0, stride gv): where the tile's samples are, how its
+// window lies in its stream, where its rows go.  RAGGED = false is the arithmetic cursor of the plain call.
+template <bool RAGGED>
+struct TileStream {
+    Cursor c;
+    mfcc_k::StreamDesc sl;   // the stream this tile belongs to (ragged: n_samples / frames of its utterance, halo 0)
+    LaunchGeom gl;
+    float *outp;
+    unsigned v;
+    int gv;
+    __device__ __forceinline__ void load(const mfcc_k::StreamDesc &s, const RaggedTables &r, int n_cep, float *out) {
+        if ((int)v < r.n_tiles) {
+            const int2 m = r.tile_map[v];
+            const RaggedChan ch = r.chans[m.x];
+            c.ch = 0;
+            c.t_in = m.y;
+            c.ptr = s.pcm + ch.pcm_off + (long long)m.y * kTileHop;
+            sl.n_samples = ch.n_samples;
+            sl.frames_per_ch = ch.frames;
+            gl.t_hi = ch.t_hi;
+            outp = out + ch.out_row * n_cep;
+        }
+    }
+    __device__ __forceinline__ void start(const mfcc_k::StreamDesc &s, const LaunchGeom &g, const RaggedTables &r,
+                                          unsigned v0, int stride, int n_cep, float *out) {
+        sl = s;
+        gl = g;
+        outp = out;
+        v = v0;
+        gv = stride;
+        if constexpr (RAGGED) {
+            sl.halo = 0;
+            gl.t_lo = 1;
+            c.ch = 0;
+            c.t_in = 0;
+            c.ptr = s.pcm;
+            load(s, r, n_cep, out);
+        } else {
+            c = cursor_of(s, g, v0);
+        }
+    }
+    __device__ __forceinline__ void next(const mfcc_k::StreamDesc &s, const RaggedTables &r, int n_cep, float *out) {
+        if constexpr (RAGGED) {
+            v += (unsigned)gv;
+            load(s, r, n_cep, out);
+        } else {
+            advance(c, gl);
+        }
+    }
+    __device__ __forceinline__ Window window() const { return window_of(c, gl); }
+};
+
 #ifndef MFCC_W12_PRIO_P1
 #define MFCC_W12_PRIO_P1 1
 #endif
@@ -111,9 +181,9 @@ __device__ unsigned long long g_stamps12[kW12Waves * 4];      // [wave]: work ev
 #define W12_LOOP_END
 #endif
 
-template <bool DENSE>
+template <bool DENSE, bool RAGGED>
 __global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, float *__restrict__ out) {
+void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, RaggedTables rag, float *__restrict__ out) {
     constexpr int kSets = SetsBf<DENSE>::N;
     __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords];
     const int tid = threadIdx.x;
@@ -132,7 +202,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
 
     // tiles of the two groups: virtual workgroups 2 w and 2 w + 1 of a grid of 2 x gridDim.x
     const unsigned va = 2u * blockIdx.x, vb = va + 1u;
-    const int n_tiles = g.tiles_per_ch * g.n_ch;                       // < 2^31 (host check)
+    const int n_tiles = RAGGED ? rag.n_tiles : g.tiles_per_ch * g.n_ch;   // < 2^30 (host check)
     const int gv = 2 * (int)gridDim.x;
     const int nA = (int)va < n_tiles ? (n_tiles - (int)va + gv - 1) / gv : 0;
     const int nB = (int)vb < n_tiles ? (n_tiles - (int)vb + gv - 1) / gv : 0;
@@ -159,7 +229,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         float *const T = Tt(gi), *const V = Vt(gi), *const Q = Qt(gi), *const S = Sf(gi);
         const int lane_slot = fr_id * kHop + lo;
         const int n_mine = gi ? nB : nA;
-        Cursor cur = cursor_of(s, g, gi ? vb : va);
+        TileStream<RAGGED> cur;
+        cur.start(s, g, rag, gi ? vb : va, gv, t.n_cep, out);
 
         lds_barrier();                                 // the parkers' prologue: S_A(0) and S_B(0) are in LDS
         // The pass-1 operands of a tile are read out of its window ONE half-step early, in the middle of the same
@@ -167,7 +238,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         // on registers instead of waiting for 32 LDS reads while the partner group does the same for its T columns.
         v2f ep[16];
         auto load_ep = [&]() {
-            const float *sp = S + lane_slot + window_of(cur, g).shift;
+            const float *sp = S + lane_slot + cur.window().shift;
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
         };
@@ -201,7 +272,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             }
             PowerBf pb;
             split_power(pw, pb);
-            advance(cur, g);
+            cur.next(s, rag, t.n_cep, out);
             load_ep();           // the next tile's operands fly during the MFMAs (after the last tile they are never used)
             f32x4 acc[kSets];
 #pragma unroll
@@ -240,33 +311,35 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         // the youngest waves of the workgroup lose the issue arbitration against the eight workers (priority, then age)
         // although they have the least to do and everybody waits for them at the barrier
         __builtin_amdgcn_s_setprio(3);
-        Cursor pa = cursor_of(s, g, va), pb = cursor_of(s, g, vb);
+        TileStream<RAGGED> pa, pb;
+        pa.start(s, g, rag, va, gv, t.n_cep, out);
+        pb.start(s, g, rag, vb, gv, t.n_cep, out);
         int ka = 0, kb = 0;                            // next tile of each stream to fetch
         // one register set per stream: a window is fetched TWO half-steps before it is parked (HBM latency under
         // load is longer than a half-step), i.e. right after the same stream's previous window has been parked
         Fetch3 fa, fb;
         bool have_a = false, have_b = false;
         if (nA > 0) {                                  // prologue: S_A(0) and S_B(0) directly
-            fetch_window3(s, window_of(pa, g), u, fa);
+            fetch_window3(pa.sl, pa.window(), u, fa);
             park_window3(Sf(0), u, fa);
-            advance(pa, g);
+            pa.next(s, rag, t.n_cep, out);
             ++ka;
         }
         if (nB > 0) {
-            fetch_window3(s, window_of(pb, g), u, fb);
+            fetch_window3(pb.sl, pb.window(), u, fb);
             park_window3(Sf(1), u, fb);
-            advance(pb, g);
+            pb.next(s, rag, t.n_cep, out);
             ++kb;
         }
         if (ka < nA) {                                 // S_A(1): parked at h = 0
-            fetch_window3(s, window_of(pa, g), u, fa);
-            advance(pa, g);
+            fetch_window3(pa.sl, pa.window(), u, fa);
+            pa.next(s, rag, t.n_cep, out);
             ++ka;
             have_a = true;
         }
         if (kb < nB) {                                 // S_B(1): parked at h = 1
-            fetch_window3(s, window_of(pb, g), u, fb);
-            advance(pb, g);
+            fetch_window3(pb.sl, pb.window(), u, fb);
+            pb.next(s, rag, t.n_cep, out);
             ++kb;
             have_b = true;
         }
@@ -281,8 +354,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 if (have_a) park_window3(Sf(0), u, fa);
                 have_a = false;
                 if (ka < nA) {
-                    fetch_window3(s, window_of(pa, g), u, fa);
-                    advance(pa, g);
+                    fetch_window3(pa.sl, pa.window(), u, fa);
+                    pa.next(s, rag, t.n_cep, out);
                     ++ka;
                     have_a = true;
                 }
@@ -290,8 +363,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 if (have_b) park_window3(Sf(1), u, fb);
                 have_b = false;
                 if (kb < nB) {
-                    fetch_window3(s, window_of(pb, g), u, fb);
-                    advance(pb, g);
+                    fetch_window3(pb.sl, pb.window(), u, fb);
+                    pb.next(s, rag, t.n_cep, out);
                     ++kb;
                     have_b = true;
                 }
@@ -342,7 +415,9 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
 #pragma unroll
         for (int i = 0; i < kAextra; ++i) ax[i] = t.a_extra[(0 * kAextra + i) * 64 + lane];
         const int lane_off = lo * t.n_cep + 4 * q;
-        Cursor ta = cursor_of(s, g, va), tb = cursor_of(s, g, vb);
+        TileStream<RAGGED> ta, tb;
+        ta.start(s, g, rag, va, gv, t.n_cep, out);
+        tb.start(s, g, rag, vb, gv, t.n_cep, out);
         lds_barrier();
         lds_barrier();
         W12_LOOP_BEGIN
@@ -368,9 +443,9 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     d0 = MFCC_MFMA(ax[r], l0[r], d0);
                     d1 = MFCC_MFMA(ax[4 + r], l1[r], d1);
                 }
-                Cursor &c = gi ? tb : ta;
-                dct_store(s, t, l0, l1, d0, d1, ax, c, lo, q, lane_off, out);
-                advance(c, g);
+                TileStream<RAGGED> &c = gi ? tb : ta;
+                dct_store(c.sl, t, l0, l1, d0, d1, ax, c.c, lo, q, lane_off, c.outp);
+                c.next(s, rag, t.n_cep, out);
             }
             W12_T1(h);
             lds_barrier();
@@ -404,10 +479,54 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense
     if (g.t_lo < 0) g.t_lo = 0;
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
+    const RaggedTables none = {nullptr, nullptr, 0};
     if (dense)
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, out);
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
     else
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, out);
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
+    return true;
+}
+
+// ---- ragged corpus, host side: per-utterance records (built by the caller in pinned memory), the tile map (built on
+// the device from them), the launch
+inline int ragged_t_hi(long long n_samples, long long tiles) {
+    if (n_samples < kSUsed) return -1;
+    const long long hi = (n_samples - kSUsed) / kTileHop;
+    return (int)(hi < tiles ? hi : tiles);
+}
+
+__global__ void ragged_tile_map_kernel(const RaggedChan *__restrict__ chans, int n_chan, int2 *__restrict__ map) {
+    for (int u = blockIdx.x; u < n_chan; u += gridDim.x) {
+        const int tiles = (chans[u].frames + kTile - 1) / kTile, t0 = chans[u].tile0;
+        for (int k = threadIdx.x; k < tiles; k += blockDim.x) map[t0 + k] = make_int2(u, k);
+    }
+}
+
+inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n_chan, int2 *d_map, int n_tiles,
+                          const FusedTables &t, bool dense, float *out, int n_cu, hipStream_t stream) {
+    if (t.win_dc != nullptr || n_tiles <= 0) return false;
+    unsigned blocks = (unsigned)(n_chan < n_cu * 8 ? n_chan : n_cu * 8);
+    hipLaunchKernelGGL(ragged_tile_map_kernel, dim3(blocks), dim3(64), 0, stream, d_chans, n_chan, d_map);
+    long long wgs = (n_tiles + 1) / 2;
+    if (wgs > n_cu) wgs = n_cu;
+    mfcc_k::StreamDesc s;
+    s.pcm = d_pcm;
+    s.ch_stride = 0;
+    s.n_samples = 0;
+    s.halo = 0;
+    s.frames_per_ch = 1;
+    s.total_frames = 0;
+    s.hop = kHop;
+    LaunchGeom g = {};
+    g.tiles_per_ch = 1;
+    g.n_ch = 0;
+    g.t_lo = 1;
+    g.t_hi = -1;
+    const RaggedTables r = {d_map, d_chans, n_tiles};
+    if (dense)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
+    else
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
     return true;
 }
 

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mfcc_hip.h"
@@ -583,6 +584,47 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
         for (size_t u = 1; u < n_utt && uniform; ++u) uniform = offsets[u + 1] - offsets[u] == n0;
         if (uniform)
             return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
+    }
+    // Float contract on the twelve-wave kernel: no packed copy at all -- per-utterance records and a tile map, the
+    // kernel reads every utterance where it lies and writes its rows where they belong (kernel_fused512_w12.hpp)
+    if (!fixed && use_fused(h) && h->fused_w12 && std::is_same<OutT, float>::value) {
+        static_assert(sizeof(mfcc_fused12::RaggedChan) == 4 * sizeof(long long), "record layout");
+        mfcc_fused12::RaggedChan *rc_host = reinterpret_cast<mfcc_fused12::RaggedChan *>(desc);   // 4 long longs each
+        long long n_tiles = 0;
+        for (size_t u = 0; u < n_utt; ++u) {
+            const size_t n = offsets[u + 1] - offsets[u];
+            const size_t nf = frame_offsets[u + 1] - frame_offsets[u];
+            const long long tiles = (long long)((nf + mfcc_fused::kTile - 1) / mfcc_fused::kTile);
+            mfcc_fused12::RaggedChan c;
+            c.pcm_off = (long long)offsets[u];
+            c.out_row = (long long)frame_offsets[u];
+            c.n_samples = (int)n;
+            c.frames = (int)nf;
+            c.t_hi = mfcc_fused12::ragged_t_hi((long long)n, tiles);
+            c.tile0 = (int)n_tiles;
+            rc_host[u] = c;
+            n_tiles += tiles;
+            if (n >= (size_t(1) << 31)) n_tiles = (1ll << 40);          // an utterance beyond the record's int fields
+        }
+        if (n_tiles < (1ll << 30)) {
+            const size_t chan_bytes = n_utt * sizeof(mfcc_fused12::RaggedChan);
+            const size_t map_off = (chan_bytes + 255) & ~size_t(255);
+            rc = ensure(h, &h->d_in, &h->d_in_bytes, map_off + size_t(n_tiles) * sizeof(int2) + 64);
+            if (rc) return rc;
+            if ((rc = scratch_acquire(h))) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->d_in, rc_host, chan_bytes, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipEventRecord(pd->copied, h->stream));
+            pd->in_flight = true;
+            auto *d_chans = static_cast<const mfcc_fused12::RaggedChan *>(h->d_in);
+            int2 *d_map = reinterpret_cast<int2 *>(static_cast<char *>(h->d_in) + map_off);
+            if (mfcc_fused12::launch_ragged(d_pcm, d_chans, (int)n_utt, d_map, (int)n_tiles, h->fu, h->fused_dense,
+                                            reinterpret_cast<float *>(d_out), h->n_cu, h->stream)) {
+                HIP_TRY(h, hipGetLastError());
+                return scratch_release(h);
+            }
+            // not launched (cannot happen once fused_w12 is set): rebuild the pack descriptors below
+            return MFCC_HIP_ERROR_OTHER;
+        }
     }
     const size_t F = pos / hop, len = pos + nfft + hop;
     desc[4 * last_with_frames + 3] = (long long)len;     // the last one also zeroes the tail of the stream
