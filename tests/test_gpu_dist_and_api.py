@@ -1,5 +1,7 @@
 """The real MFCC handle wired into mfcc_amd.dist's frame-range sharding (every shard of every plan on one GPU),
 small float transforms on the generic kernel, and the argument checks of the device path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,3 +76,42 @@ def test_device_path_refuses_a_bad_out_tensor(mfcc_amd):
             m.process(x, halo=2)
         # after a device-path call the handle is back on its own stream: a host-path call still works
         assert np.array_equal(m.process(x.cpu().numpy()), ref.cpu().numpy())
+
+
+def test_four_wave_form_of_the_fused_512_kernel_still_agrees(mfcc_amd, wav_pcm, tmp_path):
+    """`MFCC_HIP_FUSED512=w4` (read at handle creation) keeps the four-wave form of the fused 512 kernel, which otherwise
+    only runs for the double-precision DC instantiation: same tables and codelets, another staging -- the results agree
+    with the twelve-wave form to fp32 rounding and with the notebook to the contract."""
+    import subprocess
+    import sys
+    out = tmp_path / "w4.npy"
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import mfcc_amd\n"
+            "from scipy.io import wavfile\n"
+            "sr, x = wavfile.read(%r)\n"
+            "rows = []\n"
+            "for kw in (dict(nfilters=32, nceptrums=32), dict(nfilters=32, nceptrums=13, samplerate=8000), dict(nfilters=16, nceptrums=16)):\n"
+            "    with mfcc_amd.MFCC(nfft=512, pad_mode='stream', **kw) as m:\n"
+            "        assert m.kernel_name() == 'mfcc_fused512_kernel', m.kernel_name()\n"
+            "        rows.append(m.process(np.stack([x, x[::-1].copy()])))\n"
+            "np.save(%r, np.concatenate([r.reshape(-1) for r in rows]))\n"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f2bjrop1.0.wav"), str(out)))
+    env = dict(os.environ, MFCC_HIP_FUSED512="w4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    w4 = np.load(out)
+    rows, refs = [], []
+    x2 = np.stack([wav_pcm, wav_pcm[::-1].copy()])
+    for kw, okw in ((dict(nfilters=32, nceptrums=32), dict(n_cep=32)),
+                    (dict(nfilters=32, nceptrums=13, samplerate=8000), dict(n_cep=13, sample_rate=8000)),
+                    (dict(nfilters=16, nceptrums=16), dict(n_cep=16, n_mel=16))):
+        with mfcc_amd.MFCC(nfft=512, pad_mode="stream", **kw) as m:
+            assert m.kernel_name() == "mfcc_fused512_w12_kernel"
+            rows.append(m.process(x2))
+        refs.append(mf.mfcc_float_ref(x2, pad_mode="stream", **okw))
+    w12 = np.concatenate([r.reshape(-1) for r in rows])
+    ref = np.concatenate([r.reshape(-1) for r in refs])
+    scale = np.abs(ref).max()
+    assert w4.shape == w12.shape == ref.shape
+    assert np.abs(w4 - w12).max() / scale < 2e-5
+    assert np.abs(w4 - ref).max() / scale <= TOL and np.abs(w12 - ref).max() / scale <= TOL
