@@ -131,6 +131,11 @@ struct FusedTables {
                           // relative error into an absolute one, and an fp32 sum is then off by 1e-6 rms / |X[0]|
                           // (measured: 2.2 in log2 units at |X[0]| = 5e-6 rms, profiles/r02_dc_band.json) -- so bin 0
                           // alone is accumulated in double (every other bin is complex and does not cancel that way)
+    // twelve-wave form of the DC path: the workers' mel weights with bin 0 taken out, the window in double in sample
+    // order (hamming[n] / 32, n = 0 .. 256: the window is symmetric about 256), bin 0's weight per filter
+    const uint32_t *a_mel_bf_nodc;
+    const double *win_dc_lin;
+    const float *w_dc;    // [32]
     int n_cep;
     int n_mel;            // 32, or 16: block 1 does not exist (its zero sums must not reach the DCT as -inf * 0)
 };
@@ -252,7 +257,9 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     // block blk[s] at K slots j = 0..7 <-> bin(wv, l >> 4, kGrpK2[grp[s]][j]); dword d = slots (2 d, 2 d + 1)
     constexpr int kSets = SetsBf<DENSE>::N;
     std::vector<float> abf(size_t(kWaves) * kSets * 2 * 4 * 64, 0.0f);      // uint32 payload, moved as floats
-    {
+    std::vector<float> abf_nodc(abf.size(), 0.0f);                           // the same with bin 0's weights taken out
+    bool covered_ok = true;
+    auto make_abf = [&](std::vector<float> &dst, bool zero_dc) {
         auto bf16_round = [](float v) -> uint32_t {                          // round to nearest even, like v_cvt_pk_bf16_f32
             uint32_t u;
             std::memcpy(&u, &v, 4);
@@ -276,7 +283,7 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
                         float wgt = 0.0f;
                         if (!(k1 == 0 && k2 > 8)) {
                             const int bin = k2 < 8 ? k1 + 32 * k2 : 32 * (16 - k2) - k1;
-                            wgt = float(md[size_t(filt) * 257 + bin] * inv);
+                            wgt = (zero_dc && bin == 0) ? 0.0f : float(md[size_t(filt) * 257 + bin] * inv);
                             cov2[size_t(filt) * 257 + bin] = 1;
                         }
                         hi[j] = bf16_round(wgt);
@@ -284,15 +291,18 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
                     }
                     for (int d = 0; d < 4; ++d) {
                         const uint32_t vh = hi[2 * d] | (hi[2 * d + 1] << 16), vl = lo[2 * d] | (lo[2 * d + 1] << 16);
-                        std::memcpy(&abf[((size_t(wv) * kSets + st) * 2 + 0) * 256 + d * 64 + l], &vh, 4);
-                        std::memcpy(&abf[((size_t(wv) * kSets + st) * 2 + 1) * 256 + d * 64 + l], &vl, 4);
+                        std::memcpy(&dst[((size_t(wv) * kSets + st) * 2 + 0) * 256 + d * 64 + l], &vh, 4);
+                        std::memcpy(&dst[((size_t(wv) * kSets + st) * 2 + 1) * 256 + d * 64 + l], &vl, 4);
                     }
                 }
         // the sets must cover what the fp32 schedule covers (bins 16 mod 32 come from column 16 either way)
         for (int f = 0; f < kMel; ++f)
             for (int k = 0; k < 257; ++k)
-                if (md[size_t(f) * 257 + k] != 0.0 && !cov2[size_t(f) * 257 + k] && (k & 31) != 16) return false;
-    }
+                if (md[size_t(f) * 257 + k] != 0.0 && !cov2[size_t(f) * 257 + k] && (k & 31) != 16) covered_ok = false;
+    };
+    make_abf(abf, false);
+    make_abf(abf_nodc, true);
+    if (!covered_ok) return false;
     blob.clear();
     put(win); put(tw); put(amel); put(aext); put(abf);
     // double-precision window rows for the DC bin (8-byte aligned: everything before is a multiple of 8 bytes)
@@ -302,6 +312,17 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     size_t off = blob.size();
     blob.resize(off + wd.size() * 8);
     std::memcpy(blob.data() + off, wd.data(), wd.size() * 8);
+    // ... and for the twelve-wave form of the DC path: the window in sample order (n = 0 .. 256, padded to 264), the
+    // weights without bin 0, bin 0's weight per filter
+    std::vector<double> wl(264, 0.0);
+    for (int n = 0; n <= 256; ++n) wl[n] = w[n] / 32.0;
+    off = blob.size();
+    blob.resize(off + wl.size() * 8);
+    std::memcpy(blob.data() + off, wl.data(), wl.size() * 8);
+    put(abf_nodc);
+    std::vector<float> wdc(32, 0.0f);
+    for (int f = 0; f < kMel; ++f) wdc[f] = float(md[size_t(f) * 257] * inv);
+    put(wdc);
     return true;
 }
 
@@ -316,8 +337,15 @@ inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, bool dc
     t.a_mel = f;                f += kWaves * kAmel * 64;
     t.a_extra = f;              f += kWaves * kAextra * 64;
     t.a_mel_bf = reinterpret_cast<const uint32_t *>(f);
-    f += kWaves * (dense ? SetsBf<true>::N : SetsBf<false>::N) * 2 * 4 * 64;
+    const int n_abf = kWaves * (dense ? SetsBf<true>::N : SetsBf<false>::N) * 2 * 4 * 64;
+    f += n_abf;
     t.win_dc = dc_exact ? reinterpret_cast<const double *>(f) : nullptr;
+    f += 2 * 16 * 32;
+    t.win_dc_lin = reinterpret_cast<const double *>(f);
+    f += 2 * 264;
+    t.a_mel_bf_nodc = reinterpret_cast<const uint32_t *>(f);
+    f += n_abf;
+    t.w_dc = f;
 }
 
 // ---- device

@@ -28,7 +28,9 @@
 //            pass 2); HBM latency under load is longer than a half-step, hence the two half-steps of lead
 //   column 16 at h: the group in pass 2 (its V was written in h - 1); its partial sums go to Q slot 4 of the group
 //   tail at h: the group that was in pass 2 at h - 1 (Q complete at the barrier; rewritten only at h + 1)
-// LDS (114.5 KB): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
+// DCX (a filter with weight on bin 0, kernel_fused512.hpp): pass 1 also sums bin 0 of the lane's 32 samples in double
+// (window rows in double out of LDS); the tail adds the 16 partial sums of a frame and the bin's weight x |X[0]|^2.
+// LDS (114.5 KB; 127 KB with DCX): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
 // 2 w, group B 2 w + 1 of the 4-wave form's tile order.
 #pragma once
 
@@ -43,6 +45,10 @@ constexpr int kQSlots = 5;                          // 4 workers + column 16
 constexpr int kQGroupWords = kQSlots * 2 * 256;
 constexpr int kGroupWords = kTile * kTFrame + kTile * kVStride + kQGroupWords + kSUsed;
 constexpr int kW12LdsWords = 2 * kGroupWords;
+// DCX: the double-precision window rows [16 n2][kWdRow] and the workers' partial DC sums [group][tile parity][16 frames]
+// [kDcRow] (strides as in the four-wave kernel: conflict-free 16-byte / 8-byte reads)
+constexpr int kDcTileWords = 2 * kTile * kDcRow;
+constexpr int kDcLdsWords = 2 * 16 * kWdRow + 2 * 2 * kDcTileWords;
 constexpr int kParkers = 128, kParkPieces = 3;      // waves 8, 9: 128 lanes x 3 pieces of 8 samples = the 3072-slot window
 static_assert(kParkers * kParkPieces * 8 == kSUsed, "window pieces");
 
@@ -181,11 +187,16 @@ __device__ unsigned long long g_stamps12[kW12Waves * 4];      // [wave]: work ev
 #define W12_LOOP_END
 #endif
 
-template <bool DENSE, bool RAGGED>
+template <bool DENSE, bool RAGGED, bool DCX>
 __global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, RaggedTables rag, float *__restrict__ out) {
     constexpr int kSets = SetsBf<DENSE>::N;
-    __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords];
+    __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords + (DCX ? kDcLdsWords : 0)];
+    double *const Wd = reinterpret_cast<double *>(lds + kW12LdsWords);     // DCX: window rows in double
+    double *const DcT = Wd + 16 * kWdRow;                                   // DCX: [group][tile parity][16][kDcRow]
+    if constexpr (DCX) {
+        for (int i = threadIdx.x; i < 16 * 32; i += 64 * kW12Waves) Wd[(i >> 5) * kWdRow + (i & 31)] = t.win_dc[i];
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,8 +234,10 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         for (int st = 0; st < kSets; ++st)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                ah[st][d] = t.a_mel_bf[((wi * kSets + st) * 2 + 0) * 256 + d * 64 + lane];
-                al[st][d] = t.a_mel_bf[((wi * kSets + st) * 2 + 1) * 256 + d * 64 + lane];
+                // DCX: bin 0 comes from the helpers' double sum, so the workers' weights leave it out
+                const uint32_t *abf = DCX ? t.a_mel_bf_nodc : t.a_mel_bf;
+                ah[st][d] = abf[((wi * kSets + st) * 2 + 0) * 256 + d * 64 + lane];
+                al[st][d] = abf[((wi * kSets + st) * 2 + 1) * 256 + d * 64 + lane];
             }
         float *const T = Tt(gi), *const V = Vt(gi), *const Q = Qt(gi), *const S = Sf(gi);
         const int lane_slot = fr_id * kHop + lo;
@@ -244,7 +257,24 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         };
         if (n_mine > 0) load_ep();                     // tile 0 (group B idles through h = 0 with its operands loaded)
         lds_barrier();                                 // second prologue barrier: the parkers may now re-park S_A (h = 0)
+        int k_tile = 0;                                // index of the tile in pass 1 (its parity picks the DC buffer)
         auto pass1 = [&]() {
+            if constexpr (DCX) {
+                // bin 0 of this lane's 32 samples in double (the same sum as the four-wave kernel's DCX path); pass 1
+                // is the shorter phase of a half-step, so this rides in its slack.  The tail adds the 16 partial sums
+                // of a frame two half-steps later.
+                const double *wr = Wd + lo * kWdRow;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; m += 2) {
+                    a0 = __builtin_fma(wr[2 * m + 0], (double)ep[m][0], a0);
+                    a1 = __builtin_fma(wr[2 * m + 1], (double)ep[m][1], a1);
+                    a2 = __builtin_fma(wr[2 * m + 2], (double)ep[m + 1][0], a2);
+                    a3 = __builtin_fma(wr[2 * m + 3], (double)ep[m + 1][1], a3);
+                }
+                DcT[(gi * 2 + (k_tile & 1)) * (kTile * kDcRow) + fr_id * kDcRow + lo] = (a0 + a1) + (a2 + a3);
+                ++k_tile;
+            }
             // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
             // (the longer of the two phases: it gets the SIMD's issue priority over the partner group's pass 2,
             // whichever of the two waves is older -- measured: 2000 clocks per half-step instead of 2400)
@@ -418,6 +448,15 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         TileStream<RAGGED> ta, tb;
         ta.start(s, g, rag, va, gv, t.n_cep, out);
         tb.start(s, g, rag, vb, gv, t.n_cep, out);
+        // bin 0's weight in this lane's eight filters (4 q + r of block 0, 16 + 4 q + r of block 1)
+        f32x4 wdc0 = zero, wdc1 = zero;
+        if constexpr (DCX) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wdc0[r] = t.w_dc[4 * q + r];
+                wdc1[r] = t.w_dc[16 + 4 * q + r];
+            }
+        }
         lds_barrier();
         lds_barrier();
         W12_LOOP_BEGIN
@@ -428,8 +467,21 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             const int k = (h & 1) ? (h - 3) / 2 : h / 2 - 1;
             if (h >= 2 && k >= 0 && k < (gi ? nB : nA)) {
                 const f32x4 *Q4 = reinterpret_cast<const f32x4 *>(Qt(gi)) + lane;
-                const f32x4 m0 = ((Q4[0 * 64] + Q4[2 * 64]) + (Q4[4 * 64] + Q4[6 * 64])) + Q4[8 * 64];
-                const f32x4 m1 = ((Q4[1 * 64] + Q4[3 * 64]) + (Q4[5 * 64] + Q4[7 * 64])) + Q4[9 * 64];
+                f32x4 m0 = ((Q4[0 * 64] + Q4[2 * 64]) + (Q4[4 * 64] + Q4[6 * 64])) + Q4[8 * 64];
+                f32x4 m1 = ((Q4[1 * 64] + Q4[3 * 64]) + (Q4[5 * 64] + Q4[7 * 64])) + Q4[9 * 64];
+                if constexpr (DCX) {                   // bin 0 of frame lo: the workers' 16 partial sums, in double
+                    const double *dr = DcT + (gi * 2 + (k & 1)) * (kTile * kDcRow) + lo * kDcRow;
+                    double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; n2 += 2) {
+                        x0 += dr[n2];
+                        x1 += dr[n2 + 1];
+                    }
+                    x0 += x1;
+                    const float p0 = (float)(x0 * x0);
+                    m0 += wdc0 * p0;
+                    m1 += wdc1 * p0;
+                }
                 f32x4 l0, l1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -459,7 +511,7 @@ inline const char *kernel_name() { return "mfcc_fused512_w12_kernel"; }
 // returns false when the problem does not fit (then the 4-wave kernel runs)
 inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense, float *out, int n_cu,
                    hipStream_t stream) {
-    if (t.win_dc != nullptr) return false;               // the double-precision DC path lives in the 4-wave kernel
+    const bool dcx = t.win_dc != nullptr;                // a filter has weight on bin 0: that bin in double (dense sets)
     const long long tiles_per_ch = (s.frames_per_ch + kTile - 1) / kTile;
     const long long n_ch = s.total_frames / s.frames_per_ch;
     const long long n_tiles = tiles_per_ch * n_ch;
@@ -480,10 +532,12 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
     const RaggedTables none = {nullptr, nullptr, 0};
-    if (dense)
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
+    if (dcx)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, false, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
+    else if (dense)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, false, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
     else
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, false, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
     return true;
 }
 
@@ -504,7 +558,8 @@ __global__ void ragged_tile_map_kernel(const RaggedChan *__restrict__ chans, int
 
 inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n_chan, int2 *d_map, int n_tiles,
                           const FusedTables &t, bool dense, float *out, int n_cu, hipStream_t stream) {
-    if (t.win_dc != nullptr || n_tiles <= 0) return false;
+    if (n_tiles <= 0) return false;
+    const bool dcx = t.win_dc != nullptr;
     unsigned blocks = (unsigned)(n_chan < n_cu * 8 ? n_chan : n_cu * 8);
     hipLaunchKernelGGL(ragged_tile_map_kernel, dim3(blocks), dim3(64), 0, stream, d_chans, n_chan, d_map);
     long long wgs = (n_tiles + 1) / 2;
@@ -523,10 +578,12 @@ inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n
     g.t_lo = 1;
     g.t_hi = -1;
     const RaggedTables r = {d_map, d_chans, n_tiles};
-    if (dense)
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
+    if (dcx)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, true, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
+    else if (dense)
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, true, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
     else
-        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
+        hipLaunchKernelGGL((mfcc_fused512_w12_kernel<false, true, false>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
     return true;
 }
 

@@ -344,7 +344,7 @@ int build_tables(mfcc_hip_handle *h) {
     {
         // diagnostic override for A/B runs: MFCC_HIP_FUSED512=w4 keeps the four-wave form
         const char *e = std::getenv("MFCC_HIP_FUSED512");
-        h->fused_w12 = h->fused_ok && !fused_dcx && !(e && std::strcmp(e, "w4") == 0);
+        h->fused_w12 = h->fused_ok && !(e && std::strcmp(e, "w4") == 0);
     }
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
     if (h->fixed512_ok) {
