@@ -17,10 +17,19 @@
 //  * the 9 stages run as three rounds of three stages on 8 register-resident values per lane (index
 //    bits 0-2, 3-5, 6-8), with two transposes through LDS instead of nine stage round trips; the
 //    twiddles of a round depend on the lane only and live in registers for the whole kernel;
+//  * the bit-reversed load is free: lane l computes pre-emphasis and window of the samples
+//    bitrev6(l) + 64 bitrev3(r) themselves, straight from the staged raw samples;
 //  * the last stage computes only the outputs that are read out (bins 0..255);
+//  * the filterbank's products (two per bin, 490 at 16 kHz) are dealt out evenly: a filter's row is cut
+//    into pieces of at most `chunk` bins, one piece per lane (63 lanes at chunk 10), and the pieces of a
+//    filter are added up with a segmented shuffle reduction -- 64-bit integer sums, any order is exact;
 //  * in the DCT's 128-point FFT every even input is 0, so the lower half of the bit-reversed array
-//    stays 0 until the last stage: stages 0-5 are a 64-point FFT of the upper half, one value per
-//    lane, partners exchanged with lane shuffles, and the last stage is one rotation per output.
+//    stays 0 until the last stage: stages 0-5 are a 64-point FFT of the upper half and the last stage
+//    is one rotation per output;
+//  * log2 and that 64-point FFT run once per PAIR of frames: a frame's 32 filterbank sums wait in LDS
+//    for the next frame's, then each half of the wave takes one frame -- one log2 per lane, and the FFT
+//    with two values per lane: stage 0 pairs them in the lane, each later stage swaps one value with the
+//    lane 2^(st-1) away (ds_swizzle) so that the butterfly is again inside the lane.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,21 +45,21 @@ namespace mfcc_fixed512 {
 
 constexpr int kNfft = 512, kMel = 32, kWaves = 4;
 constexpr int kXWords = 512 + 64;        // transpose buffer: index i lives at i + 8 (i >> 6)
-constexpr int kMelWMax = 1024;           // packed filterbank weights held in LDS (sum of row lengths, + 8 slack)
 constexpr int kRawWords = 65 * 4;        // raw-sample staging: 65 aligned 16-byte pieces cover a frame + history
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int16_t __attribute__((may_alias)) i16_alias;     // LDS staged as 16-byte pieces, read back as samples
 
 struct Tables {
-    const int *curve8;        // [64 lanes][8]   window curve of sample lane + 64 m
+    const int *curve8;        // [64 lanes][8]   window curve of sample bitrev6(lane) + 64 bitrev3(r)
     const uint32_t *tw_r2;    // [8 lo3][7][2]   round-2 twiddles (stages 3, 4, 5) as dot2 operand pairs
     const uint32_t *tw_r3;    // [64 lanes][7][2] round-3 twiddles (stages 6, 7, 8)
-    const uint32_t *tw_dct;   // [64 lanes][7][2] DCT FFT: stages 0-5 of the upper half + last-stage rotation
+    const uint32_t *tw_dct;   // [32 lanes][16] DCT FFT, two values per lane: stages 1-5 (pairs), last-stage rotations, indices
     uint32_t tw64a, tw64b, tw192a, tw192b;   // stage-2 twiddles T[64], T[192]
-    const int *mel_start, *mel_count, *mel_off;
-    const uint32_t *mel_w;
-    int mel_shift, mel_w_total, n_cep;
+    const int4 *mel_lane;     // [64 lanes] piece of a filter row: first bin, -, (filter | head << 8), last lane of the filter
+    const uint32_t *mel_wl;   // [chunk][64 lanes] the piece's weights (x 2^-30), 0 past its end
+    int mel_chunk, mel_span;  // bins per piece (kMelChunk or less); lanes of the widest filter - 1
+    int mel_shift, n_cep;
 };
 
 inline bool supported(int nfft, int n_mel, int n_cep) { return nfft == kNfft && n_mel == kMel && n_cep >= 1 && n_cep <= kMel; }
@@ -72,9 +81,12 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
         if (re[k] > 16384 || re[k] < -16384 || im[k] > 16384 || im[k] < -16384) return false;
     if (re[0] != 16384 || im[0] != 0 || re[128] != 0 || im[128] != -16384) return false;   // stages 0-1 are mult-free
     std::vector<int> c8(64 * 8);
-    for (int l = 0; l < 64; ++l)
-        for (int m = 0; m < 8; ++m) c8[l * 8 + m] = cv[l + 64 * m];
-    std::vector<uint32_t> r2(8 * 7 * 2), r3(64 * 7 * 2), rd(64 * 7 * 2);
+    for (int l = 0; l < 64; ++l) {
+        int b6 = 0;
+        for (int k = 0; k < 6; ++k) b6 |= ((l >> k) & 1) << (5 - k);
+        for (int r = 0; r < 8; ++r) c8[l * 8 + r] = cv[b6 + 64 * (((r & 1) << 2) | (r & 2) | (r >> 2))];
+    }
+    std::vector<uint32_t> r2(8 * 7 * 2), r3(64 * 7 * 2), rd(32 * 16);
     auto put_tw = [&](std::vector<uint32_t> &v, size_t at, const std::vector<int> &R, const std::vector<int> &I, int ta) {
         tw_pair(R[ta], I[ta], v[at], v[at + 1]);
     };
@@ -93,13 +105,41 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
     }
     tw_pair(re[64], im[64], tw_s2[0], tw_s2[1]);
     tw_pair(re[192], im[192], tw_s2[2], tw_s2[3]);
-    // DCT: 128-point FFT, stage s of the element at 64 + e: j = e & (2^s - 1), ta = (j << (6 - s)) & 63
+    // DCT: 128-point FFT (fft.py:310-331 again), upper half only.  Element e of that half (array index 64 + e) starts
+    // as u[bitrev6(e)], u[m] = x[m] (m < 32), x[63 - m] (m >= 32).  Lane l starts with elements 2l, 2l + 1; before
+    // stage st >= 1 the lanes l and l ^ 2^(st-1) swap one value (the lower lane its second, the upper its first), so
+    // that every lane again holds a butterfly's x0 and x1.  Stage s of element e: j = e mod 2^s, ta = (j << (6-s)) & 63.
+    // Per lane: [2(st-1)], [2(st-1)+1] operand pair of stage st; [10], [11] last-stage rotation (ta = e) of the two
+    // final elements; [12] = load index 0 | load index 1 << 8 | final element 0 << 16 | final element 1 << 24.
     std::vector<int> dr, di;
     fx_twiddles(4 * kMel, dr, di);                    // 64 entries
-    for (int e = 0; e < 64; ++e) {
-        size_t at = size_t(e) * 14;
-        for (int s = 0; s < 6; ++s) put_tw(rd, at + 2 * s, dr, di, ((e & ((1 << s) - 1)) << (6 - s)) & 63);
-        put_tw(rd, at + 12, dr, di, e & 63);          // last stage: i0 = e, ta = e
+    {
+        int el[32][2];
+        auto br6 = [](int e) { int b = 0; for (int k = 0; k < 6; ++k) b |= ((e >> k) & 1) << (5 - k); return b; };
+        for (int l = 0; l < 32; ++l) {
+            el[l][0] = 2 * l; el[l][1] = 2 * l + 1;
+            const int m0 = br6(2 * l), m1 = br6(2 * l + 1);
+            rd[l * 16 + 12] = uint32_t(m0 < 32 ? m0 : 63 - m0) | uint32_t(m1 < 32 ? m1 : 63 - m1) << 8;
+        }
+        if (dr[0] != 16384 || di[0] != 0) return false;       // stage 0 is mult-free
+        for (int st = 1; st < 6; ++st) {
+            const int mask = 1 << (st - 1);
+            int nx[32][2];
+            for (int l = 0; l < 32; ++l) {
+                const int pl = l ^ mask;
+                if (!(l & mask)) { nx[l][0] = el[l][0]; nx[l][1] = el[pl][0]; }
+                else             { nx[l][0] = el[pl][1]; nx[l][1] = el[l][1]; }
+                if ((nx[l][0] & (1 << st)) || nx[l][1] != (nx[l][0] | (1 << st))) return false;
+                put_tw(rd, size_t(l) * 16 + 2 * (st - 1), dr, di, ((nx[l][0] & ((1 << st) - 1)) << (6 - st)) & 63);
+            }
+            std::memcpy(el, nx, sizeof(el));
+        }
+        for (int l = 0; l < 32; ++l) {
+            uint32_t a, b;
+            tw_pair(dr[el[l][0] & 63], di[el[l][0] & 63], a, b); rd[l * 16 + 10] = a;
+            tw_pair(dr[el[l][1] & 63], di[el[l][1] & 63], a, b); rd[l * 16 + 11] = a;
+            rd[l * 16 + 12] |= uint32_t(el[l][0]) << 16 | uint32_t(el[l][1]) << 24;
+        }
     }
     auto put = [&](const void *p, size_t n) {
         size_t off = blob.size();
@@ -112,6 +152,40 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
     put(r3.data(), r3.size() * 4);
     put(rd.data(), rd.size() * 4);
     return true;
+}
+
+// host: the filterbank rows (tables.hpp: pack_rows) cut into pieces of `chunk` bins, one per lane -- the smallest
+// chunk that fits 64 lanes.  lanes: 4 ints per lane, see Tables::mel_lane; wl: the weights, [kMelChunk][64].
+constexpr int kMelChunk = 12;            // bins per lane the kernel is unrolled for (10 are needed at 16 kHz)
+constexpr int kMelSpanMax = 7;           // three doubling steps of the segmented reduction
+inline bool build_mel_lanes(const std::vector<int> &start, const std::vector<int> &count, const std::vector<int> &off,
+                            const std::vector<uint32_t> &w, std::vector<int> &lanes, std::vector<uint32_t> &wl,
+                            int &chunk, int &span) {
+    const int nf = (int)start.size();
+    for (chunk = 1; chunk <= kMelChunk; ++chunk) {
+        int need = 0;
+        for (int f = 0; f < nf; ++f) need += count[f] > 0 ? (count[f] + chunk - 1) / chunk : 1;
+        if (need <= 64) break;
+    }
+    if (chunk > kMelChunk) return false;
+    lanes.assign(64 * 4, 0);
+    wl.assign(size_t(kMelChunk) * 64, 0u);
+    span = 0;
+    int l = 0;
+    for (int f = 0; f < nf; ++f) {
+        const int k = count[f] > 0 ? (count[f] + chunk - 1) / chunk : 1;
+        if (k - 1 > span) span = k - 1;
+        for (int i = 0; i < k; ++i, ++l) {
+            int n = count[f] - i * chunk;
+            n = n < 0 ? 0 : (n > chunk ? chunk : n);
+            lanes[l * 4 + 0] = start[f] + i * chunk;
+            lanes[l * 4 + 2] = f | ((i == 0) << 8);
+            lanes[l * 4 + 3] = l - i + k - 1;
+            for (int u = 0; u < n; ++u) wl[size_t(u) * 64 + l] = w[off[f] + i * chunk + u];
+        }
+    }
+    for (; l < 64; ++l) lanes[l * 4 + 3] = l;         // spare lanes: no bins, no filter, a segment of their own
+    return span <= kMelSpanMax;
 }
 
 inline void bind_tables(const char *b, Tables &t) {
@@ -163,6 +237,18 @@ __device__ __forceinline__ void round3(uint32_t (&x)[8], const uint32_t (&tw)[14
     for (int r = 0; r < 4; ++r) bfly(x[r], x[r + 4], tw[6 + 2 * r], tw[7 + 2 * r]);   // LAST: x[r+4] is not read out
 }
 
+// stage ST >= 1 of the DCT's 64-point FFT on two values per lane: swap one value with the lane 2^(ST-1) away
+// (ds_swizzle in bit-mask mode: xor inside each half of the wave), then the butterfly is inside the lane
+template <int ST>
+__device__ __forceinline__ void dct_stage(uint32_t &s0, uint32_t &s1, const uint32_t (&twd)[13], int lane) {
+    const bool lower = !(lane & (1 << (ST - 1)));
+    const uint32_t send = lower ? s1 : s0;
+    const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send, ((1 << (ST - 1)) << 10) | 0x1f);
+    s0 = lower ? s0 : recv;
+    s1 = lower ? recv : s1;
+    bfly(s0, s1, twd[2 * (ST - 1)], twd[2 * (ST - 1) + 1]);
+}
+
 struct FrameCursor {
     int ch;
     long long f;
@@ -200,32 +286,33 @@ __global__ __launch_bounds__(64 * kWaves)
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t xbuf[kWaves][kXWords];     // gather / transposes / power
     __shared__ __attribute__((aligned(16))) uint32_t rawbuf[kWaves][kRawWords];
-    __shared__ uint32_t melw[kMelWMax];
-    __shared__ int melv[kWaves][kMel];
+    __shared__ int melv[kWaves][2][kMel];                       // filterbank sums of a pair of frames, then their logs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *X = xbuf[wave];
     uint32_t *Rb = rawbuf[wave];
 
-    // read-only tables: filterbank weights in LDS, the rest in registers for the whole kernel
-    for (int i = tid; i < t.mel_w_total; i += 64 * kWaves) melw[i] = t.mel_w[i];
+    // read-only tables in registers for the whole kernel
     int curve[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) curve[m] = t.curve8[lane * 8 + m];
-    uint32_t tw2[14], tw3[14], twd[14];
+    uint32_t tw2[14], tw3[14], twd[13];
 #pragma unroll
     for (int i = 0; i < 14; ++i) {
         tw2[i] = t.tw_r2[(lane & 7) * 14 + i];
         tw3[i] = t.tw_r3[lane * 14 + i];
-        twd[i] = t.tw_dct[lane * 14 + i];
     }
-    // filter (lane >> 1), half (lane & 1) of its bins
-    const int filt = lane >> 1;
-    const int m_start = t.mel_start[filt], m_count = t.mel_count[filt], m_off = t.mel_off[filt];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) twd[i] = t.tw_dct[(lane & 31) * 16 + i];
+    int slot = 0;                                   // frames waiting for the paired log2 + DCT pass
+    long long row[2] = {0, 0};
+    const int4 ml = t.mel_lane[lane];               // this lane's piece of a filterbank row, and its weights
+    uint32_t mw[kMelChunk];
+#pragma unroll
+    for (int u = 0; u < kMelChunk; ++u) mw[u] = t.mel_wl[u * 64 + lane];
     const int br6 = (int)(__brev((unsigned)lane) >> 26);
-    __syncthreads();
-
+    
     // first frame of this wave; then strides of (all waves of the grid)
     const long long wid = (long long)blockIdx.x * kWaves + wave;
     FrameCursor c;
@@ -277,30 +364,19 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
             if (lane == 63) raw64 = src[lane_op + 1];
         }
 
-        // ---- pre-emphasis and window of sample a = lane + 64 m, parked as int16 for the bit-reversed gather
-        {
-            uint16_t *W = reinterpret_cast<uint16_t *>(X);
-            const i16_alias *r = R16 + first + lane;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int o = r[64 * m], x0 = r[64 * m + 1];
-                const int y = (int)(short)((x0 + (o >> 5) - o) & 0xffff);       // preemph.py:24
-                W[lane + 64 * m] = (uint16_t)(__mul24(y, curve[m]) >> 9);       // window.py:84
-            }
-        }
-        wave_fence();
-
-        // ---- FFT 512.  Bit-reversed load (fft.py:413-424): element i = 8 lane + r holds sample bitrev9(i)
+        // ---- pre-emphasis and window, already in the FFT's bit-reversed order (fft.py:413-424): element
+        // i = 8 lane + r is sample bitrev9(i) = bitrev6(lane) + 64 bitrev3(r); imag = 0
         uint32_t x[8];
         {
-            const uint16_t *W = reinterpret_cast<const uint16_t *>(X);
+            const i16_alias *r16 = R16 + first + br6;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int br3 = ((r & 1) << 2) | (r & 2) | (r >> 2);
-                x[r] = W[(br3 << 6) + br6];                                     // imag = 0
+                const int m = ((r & 1) << 2) | (r & 2) | (r >> 2);
+                const int o = r16[64 * m], x0 = r16[64 * m + 1];
+                const int y = (int)(short)((x0 + (o >> 5) - o) & 0xffff);       // preemph.py:24
+                x[r] = (uint32_t)(__mul24(y, curve[r]) >> 9) & 0xffffu;         // window.py:84
             }
         }
-        wave_fence();
         // round 1: stages 0, 1, 2 on index bits 0, 1, 2; twiddle index (j << (8 - s)): T[0], T[128], T[64], T[192]
 #pragma unroll
         for (int r = 0; r < 8; r += 2) bfly_one(x[r], x[r + 1]);
@@ -338,60 +414,67 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
         }
         wave_fence();
 
-        // ---- filterbank, closed form (tables.hpp: fx_mel): two lanes per filter, then log2 (log.py:33-102)
+        // ---- filterbank, closed form (tables.hpp: fx_mel): one piece of a row per lane, pieces of a filter added
+        // up by a segmented reduction, then log2 (log.py:33-102) on the filter's first lane
         {
             unsigned long long acc = 0;
-            // four bins per trip, so that their LDS reads are in flight together
-            for (int j = (lane & 1); j < m_count; j += 8) {
-                unsigned long long part = 0;
+            const uint32_t *xp = X + ml.x;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int jj = j + 2 * u;
-                    const uint32_t w = jj < m_count ? melw[m_off + jj] : 0u;
-                    part += (unsigned long long)X[m_start + jj] * (unsigned long long)w;
+            for (int u = 0; u < kMelChunk; u += 2) {        // bins past the piece: weight 0
+                if (u < t.mel_chunk)
+                    acc += (unsigned long long)xp[u] * mw[u] + (unsigned long long)xp[u + 1] * mw[u + 1];
+            }
+#pragma unroll
+            for (int d = 1; d <= kMelSpanMax; d <<= 1) {
+                if (d <= t.mel_span) {
+                    const unsigned lo2 = (unsigned)__shfl_down((int)(unsigned)acc, d), hi2 = (unsigned)__shfl_down((int)(unsigned)(acc >> 32), d);
+                    if (lane + d <= ml.w) acc += ((unsigned long long)hi2 << 32) | lo2;
                 }
-                acc += part;
             }
-            const unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
-            const unsigned lo2 = (unsigned)__shfl_xor((int)lo, 1), hi2 = (unsigned)__shfl_xor((int)hi, 1);
-            acc += ((unsigned long long)hi2 << 32) | lo2;
-            const unsigned v = (unsigned)(acc >> t.mel_shift) & 0xFFFFu;
-            const unsigned v1 = v ? v : 1u;
-            const int msb = 31 - __clz((int)v1);
-            unsigned z = (v1 << 11) >> msb;                 // the shift-right loop of log.py:57-62 in one step
-            unsigned o = (unsigned)msb << 11;
-#pragma unroll
-            for (int cc = 0; cc < 10; ++cc) {
-                const unsigned q = __umul24(z, z);
-                const unsigned bit = (q >> 23) & 1u;
-                z = q >> (11 + bit);
-                o += bit << (10 - cc);
-            }
-            if (!(lane & 1)) melv[wave][filt] = (int)(o & 0x7FFFu);
+            if (ml.z >> 8) melv[wave][slot][ml.z & 0xff] = (int)((unsigned)(acc >> t.mel_shift) & 0xFFFFu);
         }
+        row[slot] = (long long)c.ch * g.frames_per_ch + c.f;
+        ++slot;
         wave_fence();
 
-        // ---- DCT (dct_stream.py:23-33): 128-point FFT of y[2n+1] = y[127-2n] = x[n].  Natural index 2m+1 sits
-        // at bit-reversed 64 + bitrev6(m): the upper half; element e = lane holds u[bitrev6(lane)],
-        // u[m] = x[m] (m < 32), x[63 - m] (m >= 32)
-        {
-            const int m = br6;
-            uint32_t v = (uint32_t)melv[wave][m < 32 ? m : 63 - m] & 0xffffu;
+        if (slot == 2 || !more) {
+            // ---- log2 (log.py:33-102) of both frames' sums: half h of the wave takes frame h
+            const int h = lane >> 5, l5 = lane & 31;
+            int *mv = melv[wave][h];
+            {
+                const unsigned v = (unsigned)mv[l5];
+                const unsigned v1 = v ? v : 1u;
+                const int msb = 31 - __clz((int)v1);
+                unsigned z = (v1 << 11) >> msb;             // the shift-right loop of log.py:57-62 in one step
+                unsigned o = (unsigned)msb << 11;
 #pragma unroll
-            for (int st = 0; st < 6; ++st) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)v, 1 << st);
-                const bool up = (lane >> st) & 1;             // this lane holds x1 of its butterfly
-                uint32_t p0 = up ? other : v, p1 = up ? v : other;
-                if (st == 0) bfly_one(p0, p1);
-                else bfly(p0, p1, twd[2 * st], twd[2 * st + 1]);
-                v = up ? p1 : p0;
+                for (int cc = 0; cc < 10; ++cc) {
+                    const unsigned q2 = __umul24(z, z);
+                    const unsigned bit = (q2 >> 23) & 1u;
+                    z = q2 >> (11 + bit);
+                    o += bit << (10 - cc);
+                }
+                mv[l5] = (int)(o & 0x7FFFu);
             }
-            // last stage: x0 = 0 (lower half), x1 = v, twiddle index lane; Re of y0 only
-            const int a1 = rot14(v, twd[12]);
-            if (lane < t.n_cep)
-                out[((long long)c.ch * g.frames_per_ch + c.f) * t.n_cep + lane] = (int16_t)(a1 >> 1);
+            wave_fence();
+            // ---- DCT (dct_stream.py:23-33): 128-point FFT of y[2n+1] = y[127-2n] = x[n]; see build_tables
+            {
+                uint32_t s0 = (uint32_t)mv[twd[12] & 0xff], s1 = (uint32_t)mv[(twd[12] >> 8) & 0xff];
+                bfly_one(s0, s1);
+                dct_stage<1>(s0, s1, twd, lane); dct_stage<2>(s0, s1, twd, lane); dct_stage<3>(s0, s1, twd, lane);
+                dct_stage<4>(s0, s1, twd, lane); dct_stage<5>(s0, s1, twd, lane);
+                // last stage: x0 = 0 (lower half), x1 = the element, twiddle index = its number; Re of y0 only
+                const int a0 = rot14(s0, twd[10]), a1 = rot14(s1, twd[11]);
+                const int e0 = (twd[12] >> 16) & 0xff, e1 = twd[12] >> 24;
+                if (h < slot) {
+                    int16_t *o = out + (h ? row[1] : row[0]) * t.n_cep;
+                    if (e0 < t.n_cep) o[e0] = (int16_t)(a0 >> 1);
+                    if (e1 < t.n_cep) o[e1] = (int16_t)(a1 >> 1);
+                }
+            }
+            slot = 0;
+            wave_fence();
         }
-        wave_fence();
 
         c = nc;
         q = qn;

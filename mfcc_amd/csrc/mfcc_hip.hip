@@ -254,7 +254,10 @@ int build_tables(mfcc_hip_handle *h) {
 
     // ---- fixed
     size_t o_cv = 0, o_xt = 0, o_xd = 0, o_xs = 0, o_xc = 0, o_xo = 0, o_xw = 0;
-    int x5_w_total = 0;
+    int x5_w_total = 0, x5_chunk = 0, x5_span = 0;
+    bool x5_lanes_ok = false;
+    std::vector<int> x5_lanes;
+    std::vector<uint32_t> x5_wl;
     FxMel fm;
     h->fixed_ok = fixed_supported(r);
     if (h->fixed_ok) {
@@ -277,14 +280,19 @@ int build_tables(mfcc_hip_handle *h) {
         o_cv = a.put(cv); o_xt = a.put(t1); o_xd = a.put(t2);
         o_xs = a.put(xs.start); o_xc = a.put(xs.count); o_xo = a.put(xs.off); o_xw = a.put(xw);
         x5_w_total = (int)xw.size();
+        x5_lanes_ok = mfcc_fixed512::build_mel_lanes(xs.start, xs.count, xs.off, xw, x5_lanes, x5_wl, x5_chunk, x5_span);
     }
     // ---- fused fixed-point kernel (the RTL's own configuration)
     std::vector<char> x5_blob;
     uint32_t x5_tw[4] = {0, 0, 0, 0};
-    h->fixed512_ok = h->fixed_ok && mfcc_fixed512::supported(r.nfft, r.n_mel, r.n_cep) &&
-                     x5_w_total + 8 <= mfcc_fixed512::kMelWMax && mfcc_fixed512::build_tables(x5_blob, x5_tw);
-    size_t o_x5 = 0;
-    if (h->fixed512_ok) o_x5 = a.put(x5_blob);
+    h->fixed512_ok = h->fixed_ok && mfcc_fixed512::supported(r.nfft, r.n_mel, r.n_cep) && x5_lanes_ok &&
+                     mfcc_fixed512::build_tables(x5_blob, x5_tw);
+    size_t o_x5 = 0, o_x5l = 0, o_x5w = 0;
+    if (h->fixed512_ok) {
+        o_x5 = a.put(x5_blob);
+        o_x5l = a.put(x5_lanes);
+        o_x5w = a.put(x5_wl);
+    }
 
     // ---- fused 512/170/32 kernel tables
     std::vector<char> fused_blob;
@@ -350,10 +358,11 @@ int build_tables(mfcc_hip_handle *h) {
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
         h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];
-        h->x5.mel_start = h->xt.mel_start; h->x5.mel_count = h->xt.mel_count; h->x5.mel_off = h->xt.mel_off;
-        h->x5.mel_w = h->xt.mel_w;
+        h->x5.mel_lane = reinterpret_cast<const int4 *>(b + o_x5l);
+        h->x5.mel_chunk = x5_chunk;
+        h->x5.mel_span = x5_span;
+        h->x5.mel_wl = reinterpret_cast<const uint32_t *>(b + o_x5w);
         h->x5.mel_shift = fm.shift;
-        h->x5.mel_w_total = x5_w_total;
         h->x5.n_cep = r.n_cep;
     }
     return MFCC_HIP_SUCCESS;
