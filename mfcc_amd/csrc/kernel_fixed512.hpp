@@ -368,20 +368,50 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
         // i = 8 lane + r is sample bitrev9(i) = bitrev6(lane) + 64 bitrev3(r); imag = 0
         uint32_t x[8];
         {
+            int w[8];
             const i16_alias *r16 = R16 + first + br6;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int m = ((r & 1) << 2) | (r & 2) | (r >> 2);
                 const int o = r16[64 * m], x0 = r16[64 * m + 1];
                 const int y = (int)(short)((x0 + (o >> 5) - o) & 0xffff);       // preemph.py:24
-                x[r] = (uint32_t)(__mul24(y, curve[r]) >> 9) & 0xffffu;         // window.py:84
+                w[r] = (int)(short)((__mul24(y, curve[r]) >> 9) & 0xffff);      // window.py:84
             }
-        }
-        // round 1: stages 0, 1, 2 on index bits 0, 1, 2; twiddle index (j << (8 - s)): T[0], T[128], T[64], T[192]
+            // round 1: stages 0, 1, 2 on index bits 0, 1, 2; twiddle index (j << (8 - s)): T[0], T[128], T[64], T[192].
+            // The input is real and T[0] = (16384, 0), T[128] = (0, -16384) rotate exactly ((x 16384 + 8191) >> 14
+            // == x, (-16384 x + 8191) >> 14 == -x), so the RTL's butterfly (fft.py:140-192) comes down to
+            //   T[0]   on reals a, b:   ((a + b) >> 1, 0), ((a - b) >> 1, 0)       -- 16-bit a, b: no wrap can occur
+            //   T[128] on reals a, b:   (a >> 1, (-b) >> 1), (a >> 1, b >> 1)
+            // stage 0: four T[0] butterflies on reals
 #pragma unroll
-        for (int r = 0; r < 8; r += 2) bfly_one(x[r], x[r + 1]);
-        bfly_one(x[0], x[2]); bfly_mi(x[1], x[3]); bfly_one(x[4], x[6]); bfly_mi(x[5], x[7]);
-        bfly_one(x[0], x[4]); bfly(x[1], x[5], t.tw64a, t.tw64b); bfly_mi(x[2], x[6]); bfly(x[3], x[7], t.tw192a, t.tw192b);
+            for (int r = 0; r < 8; r += 2) {
+                const int a = w[r], b = w[r + 1];
+                w[r] = (a + b) >> 1;
+                w[r + 1] = (a - b) >> 1;
+            }
+            // stage 1: (0,2), (4,6) T[0] on reals; (1,3), (5,7) T[128] on reals, complex from here on
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k += 4) {
+                const int a = w[k], b = w[k + 2];
+                w[k] = (a + b) >> 1;
+                w[k + 2] = (a - b) >> 1;
+                const int h1 = w[k + 1] >> 1, h3 = w[k + 3] >> 1, n3 = (-w[k + 3]) >> 1;
+                c[k + 1] = __builtin_amdgcn_perm((uint32_t)n3, (uint32_t)h1, 0x05040100u);     // (re, im) = (h1, n3)
+                c[k + 3] = __builtin_amdgcn_perm((uint32_t)h3, (uint32_t)h1, 0x05040100u);
+            }
+            // stage 2: (0,4) T[0] on reals, (2,6) T[128] on reals, (1,5) T[64] and (3,7) T[192] in full
+            x[0] = (uint32_t)((w[0] + w[4]) >> 1) & 0xffffu;
+            x[4] = (uint32_t)((w[0] - w[4]) >> 1) & 0xffffu;
+            {
+                const int h2 = w[2] >> 1, h6 = w[6] >> 1, n6 = (-w[6]) >> 1;
+                x[2] = __builtin_amdgcn_perm((uint32_t)n6, (uint32_t)h2, 0x05040100u);
+                x[6] = __builtin_amdgcn_perm((uint32_t)h6, (uint32_t)h2, 0x05040100u);
+            }
+            x[1] = c[1]; x[5] = c[5]; x[3] = c[3]; x[7] = c[7];
+            bfly(x[1], x[5], t.tw64a, t.tw64b);
+            bfly(x[3], x[7], t.tw192a, t.tw192b);
+        }
         // transpose 1: index i at i + 8 (i >> 6); lane (hi3, lo3) takes i = 64 hi3 + 8 r + lo3
         {
             uint32_t *w = X + lane * 8 + (lane >> 3) * 8;
