@@ -393,6 +393,28 @@ def test_fixed_other_parameters(mfcc_amd):
         assert np.array_equal(got, ref), (nfft, nfil, ncep)
 
 
+def test_fixed_fused_kernel_other_sample_rates(mfcc_amd):
+    """The fused fixed-point kernel deals the filterbank's products out in pieces whose size and count follow the
+    filter widths, i.e. the sample rate (10 bins / up to 4 lanes per filter at 16 kHz, 11 / 5 at 48 kHz: the third
+    step of the segmented reduction): every rate bit for bit against the oracle, or refused where the oracle's
+    filterbank asserts."""
+    pcm = np.concatenate([mf.synth_pcm(30000, seed=21), np.full(700, -32768, np.int16), np.full(700, 32767, np.int16)])
+    ran = 0
+    for sr in (8000, 11025, 22050, 32000, 44100, 48000):
+        with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, pad_mode="stream") as m:
+            try:
+                ref = mx.mfcc_fixed_ref(pcm, nceptrums=32, sample_rate=float(sr))
+            except AssertionError:
+                with pytest.raises(mfcc_amd.MfccHipError) as e:
+                    m.process_fixed(pcm)
+                assert e.value.code == -105, sr
+                continue
+            assert m.kernel_name(fixed=True) == "mfcc_fixed512_kernel", sr
+            assert np.array_equal(m.process_fixed(pcm), ref), sr
+            ran += 1
+    assert ran >= 4
+
+
 def test_fixed_filterbanks_the_rtl_cannot_stream_are_refused(mfcc_amd):
     """Filter points too dense for the streaming filterbank (filterbank.py:22-34,88-142): the RTL would emit fewer
     than n_mel values per frame (the oracle asserts on exactly these sets) -- UNSUPPORTED, never a made-up result."""
