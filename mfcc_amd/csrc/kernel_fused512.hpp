@@ -119,6 +119,8 @@ using mfcc_fc::preemph8;
 using mfcc_fc::lds_barrier;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+constexpr int kDcDigits = 7;
+
 struct FusedTables {
     const float *win;     // [16 n2][32 n1]   hamming[16 n1 + n2] / 64 (pre-emphasis x32, real-FFT split x2)
     const float2 *tw;     // [16 n2][16 k1]   W512^(n2 k1)
@@ -136,6 +138,12 @@ struct FusedTables {
     const uint32_t *a_mel_bf_nodc;
     const double *win_dc_lin;
     const float *w_dc;    // [32]
+    // ... and its integer form (twelve-wave kernel): X[0] = sum_m c[m] x[m] over the RAW samples x[-1 .. 511]
+    // (c[m] = w[m] - 31/32 w[m+1], the pre-emphasis folded into the window), c as 49-bit integers C = round(c 2^B) in
+    // seven balanced base-128 digits, the raw bytes as they lie in memory: one v_mfma_i32_16x16x64_i8 chain per tile,
+    // exact in int32.  [17 k-blocks][64 lanes][4 dwords] A operands; dc_consts = {2^-B, lo, hi of 128 sum(C) = hi 2^28 + lo}
+    const uint32_t *a_dc_i8;
+    const double *dc_consts;
     int n_cep;
     int n_mel;            // 32, or 16: block 1 does not exist (its zero sums must not reach the DCT as -inf * 0)
 };
@@ -323,6 +331,48 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
     std::vector<float> wdc(32, 0.0f);
     for (int f = 0; f < kMel; ++f) wdc[f] = float(md[size_t(f) * 257] * inv);
     put(wdc);
+    // bin 0 on the raw samples: e[n] = 32 x[n] - 31 x[n-1], X[0] = sum_n (w[n] / 32) e[n] = sum_{m=-1}^{511} c[m] x[m]
+    {
+        double c[513], maxc = 0.0;
+        for (int m = -1; m <= 511; ++m) {
+            c[m + 1] = (m >= 0 ? w[m] : 0.0) - (m <= 510 ? 31.0 / 32.0 * w[m + 1] : 0.0);
+            if (std::fabs(c[m + 1]) > maxc) maxc = std::fabs(c[m + 1]);
+        }
+        // seven digits in [-64, 63]: |C| <= 64 (128^7 - 1) / 127 = 2.8e14 -- 48 bits, what the double sum resolved
+        int B = 0;
+        while (std::ldexp(maxc, B + 1) < 2.7e14) ++B;
+        long long sumC = 0;
+        std::vector<uint32_t> adc(size_t(17) * 64 * 4, 0u);
+        for (int tau = 0; tau < 513; ++tau) {
+            long long C = std::llround(std::ldexp(c[tau], B));
+            sumC += C;
+            for (int j = 0; j < kDcDigits; ++j) {
+                long long r = ((C + 64) % 128 + 128) % 128 - 64;
+                C = (C - r) / 128;
+                // the lo byte of sample tau is byte k = 2 tau of the frame's span, its hi byte k = 2 tau + 1;
+                // byte k sits in k-block k / 64, lane group (k % 64) / 16, byte (k % 16) of the lane's four dwords;
+                // MFMA row j takes the lo bytes with digit j, row kDcDigits + j the hi bytes
+                for (int hi = 0; hi < 2; ++hi) {
+                    const int k = 2 * tau + hi, row = hi ? kDcDigits + j : j;
+                    const int lane = row + 16 * ((k % 64) / 16);
+                    const size_t dw = (size_t(k / 64) * 64 + lane) * 4 + (k % 16) / 4;
+                    adc[dw] |= uint32_t(uint8_t(int8_t(r))) << (8 * (k % 4));
+                }
+            }
+            if (C != 0) return false;
+        }
+        {
+            size_t o1 = blob.size();
+            blob.resize(o1 + adc.size() * 4);
+            std::memcpy(blob.data() + o1, adc.data(), adc.size() * 4);
+        }
+        // 128 sum(C) (the lo bytes are taken as lo - 128), split like the kernel's two partial sums: hi 2^28 + lo
+        const long long bias = 128 * sumC, bias_lo = ((bias % (1ll << 28)) + (1ll << 28)) % (1ll << 28);
+        const double consts[3] = {std::ldexp(1.0, -B), double(bias_lo), double((bias - bias_lo) >> 28)};
+        size_t o2 = blob.size();
+        blob.resize(o2 + sizeof(consts));
+        std::memcpy(blob.data() + o2, consts, sizeof(consts));
+    }
     return true;
 }
 
@@ -346,6 +396,10 @@ inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, bool dc
     t.a_mel_bf_nodc = reinterpret_cast<const uint32_t *>(f);
     f += n_abf;
     t.w_dc = f;
+    f += 32;
+    t.a_dc_i8 = reinterpret_cast<const uint32_t *>(f);
+    f += 17 * 64 * 4;
+    t.dc_consts = reinterpret_cast<const double *>(f);
 }
 
 // ---- device

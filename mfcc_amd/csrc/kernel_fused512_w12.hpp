@@ -28,9 +28,17 @@
 //            pass 2); HBM latency under load is longer than a half-step, hence the two half-steps of lead
 //   column 16 at h: the group in pass 2 (its V was written in h - 1); its partial sums go to Q slot 4 of the group
 //   tail at h: the group that was in pass 2 at h - 1 (Q complete at the barrier; rewritten only at h + 1)
-// DCX (a filter with weight on bin 0, kernel_fused512.hpp): pass 1 also sums bin 0 of the lane's 32 samples in double
-// (window rows in double out of LDS); the tail adds the 16 partial sums of a frame and the bin's weight x |X[0]|^2.
-// LDS (114.5 KB; 127 KB with DCX): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
+// DCX (a filter with weight on bin 0, kernel_fused512.hpp: that bin must not be summed in fp32): bin 0 is an EXACT
+// integer sum over the raw samples.  With the pre-emphasis folded into the window, X[0] = sum_m c[m] x[m] over the
+// 513 raw int16 samples x[-1 .. 511] of the frame; c is quantised to 49-bit integers held as seven balanced base-128
+// digits, and the raw samples' two bytes are int8 operands as they lie in memory (lo byte ^ 0x80 = lo - 128, signed;
+// the constant 128 sum(C) is added back): the parkers keep a raw copy R of the window next to S (shifted by one sample
+// when the frames would start in the high half of a dword), wave 10 runs one chain of 17 v_mfma_i32_16x16x64_i8 per
+// tile -- rows = digits x {lo, hi} byte, columns = the tile's 16 frames, K = the frame's 1026 bytes, accumulated
+// exactly in int32 -- and the tail combines a frame's fourteen sums in double (exactly: two partial sums below 2^53) and adds the bin's weight x |X[0]|^2.
+// (Round 2's first DC path, 32 cvt + 32 DFMA per worker lane and tile, cost 0.33 ms of 1.28; this one rides in
+// wave 10's slack.)
+// LDS (114.5 KB; 131 KB with DCX): T, V, Q (5 slots), S per group.  Virtual grid = 2 x workgroups: group A is virtual workgroup
 // 2 w, group B 2 w + 1 of the 4-wave form's tile order.
 #pragma once
 
@@ -45,19 +53,23 @@ constexpr int kQSlots = 5;                          // 4 workers + column 16
 constexpr int kQGroupWords = kQSlots * 2 * 256;
 constexpr int kGroupWords = kTile * kTFrame + kTile * kVStride + kQGroupWords + kSUsed;
 constexpr int kW12LdsWords = 2 * kGroupWords;
-// DCX: the double-precision window rows [16 n2][kWdRow] and the workers' partial DC sums [group][tile parity][16 frames]
-// [kDcRow] (strides as in the four-wave kernel: conflict-free 16-byte / 8-byte reads)
-constexpr int kDcTileWords = 2 * kTile * kDcRow;
-constexpr int kDcLdsWords = 2 * 16 * kWdRow + 2 * 2 * kDcTileWords;
+// DCX: the raw copy of a group's window (packed int16 pairs; the chain's last k-block reads up to 32 dwords past it,
+// against zero weights) and the integer sums [group][tile parity][16 rows][16 frames]
+constexpr int kRawWords = kSUsed / 2 + 32;
+constexpr int kDcBlocks = 17;                       // k-blocks of 64 bytes: 513 samples = 1026 bytes
+constexpr int kDcLdsWords = 2 * kRawWords + 2 * 2 * 256;
+typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kParkers = 128, kParkPieces = 3;      // waves 8, 9: 128 lanes x 3 pieces of 8 samples = the 3072-slot window
 static_assert(kParkers * kParkPieces * 8 == kSUsed, "window pieces");
 
 struct Fetch3 {
     i32x4 v[kParkPieces];
     int p[kParkPieces];          // dword in front of v[k]: its high half is the piece's predecessor sample
+    int odd;                     // DCX: the window's shift is odd (the frames' sample -1 lies in a low half as fetched)
 };
 
 __device__ __forceinline__ void fetch_window3(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch3 &f) {
+    f.odd = w.shift & 1;
     if (w.inside) {
         const i32x4 *g = reinterpret_cast<const i32x4 *>(w.ptr - w.shift);
         const int *g32 = reinterpret_cast<const int *>(g);
@@ -80,9 +92,25 @@ __device__ __forceinline__ void fetch_window3(const mfcc_k::StreamDesc &s, const
     }
 }
 
-__device__ __forceinline__ void park_window3(float *Sf, int u, const Fetch3 &f) {
+// RAW: also the raw copy for the integer DC sum.  Dword d of R holds the samples (2 d, 2 d + 1) of the window as
+// fetched when the shift is odd, (2 d - 1, 2 d) when it is even: either way sample -1 of frame f is the LOW half of
+// dword (shift >> 1) + 85 f.  Stored with the lo bytes' top bit flipped (lo - 128 as a signed byte).
+template <bool RAW>
+__device__ __forceinline__ void park_window3(float *Sf, int *R, int u, const Fetch3 &f) {
 #pragma unroll
-    for (int k = 0; k < kParkPieces; ++k) preemph8(f.p[k], f.v[k], Sf + 8 * (k * kParkers + u));
+    for (int k = 0; k < kParkPieces; ++k) {
+        preemph8(f.p[k], f.v[k], Sf + 8 * (k * kParkers + u));
+        if constexpr (RAW) {
+            i32x4 r = f.v[k];
+            if (!f.odd) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    r[m] = (int)__builtin_amdgcn_alignbit((unsigned)f.v[k][m], (unsigned)(m ? f.v[k][m - 1] : f.p[k]), 16u);
+            }
+            r ^= 0x00800080;                           // lo bytes: unsigned -> signed - 128 (the int8 operands' form)
+            *reinterpret_cast<i32x4 *>(R + 4 * (k * kParkers + u)) = r;
+        }
+    }
 }
 
 // cursor of virtual workgroup v
@@ -192,11 +220,8 @@ __global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(
 void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, RaggedTables rag, float *__restrict__ out) {
     constexpr int kSets = SetsBf<DENSE>::N;
     __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords + (DCX ? kDcLdsWords : 0)];
-    double *const Wd = reinterpret_cast<double *>(lds + kW12LdsWords);     // DCX: window rows in double
-    double *const DcT = Wd + 16 * kWdRow;                                   // DCX: [group][tile parity][16][kDcRow]
-    if constexpr (DCX) {
-        for (int i = threadIdx.x; i < 16 * 32; i += 64 * kW12Waves) Wd[(i >> 5) * kWdRow + (i & 31)] = t.win_dc[i];
-    }
+    int *const Rw = reinterpret_cast<int *>(lds + kW12LdsWords);           // DCX: raw windows [group][kRawWords]
+    int *const DcI = Rw + 2 * kRawWords;                                    // DCX: [group][tile parity][16 rows][16 frames]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,7 +259,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         for (int st = 0; st < kSets; ++st)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                // DCX: bin 0 comes from the helpers' double sum, so the workers' weights leave it out
+                // DCX: bin 0 comes from wave 10's integer sum, so the workers' weights leave it out
                 const uint32_t *abf = DCX ? t.a_mel_bf_nodc : t.a_mel_bf;
                 ah[st][d] = abf[((wi * kSets + st) * 2 + 0) * 256 + d * 64 + lane];
                 al[st][d] = abf[((wi * kSets + st) * 2 + 1) * 256 + d * 64 + lane];
@@ -257,24 +282,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         };
         if (n_mine > 0) load_ep();                     // tile 0 (group B idles through h = 0 with its operands loaded)
         lds_barrier();                                 // second prologue barrier: the parkers may now re-park S_A (h = 0)
-        int k_tile = 0;                                // index of the tile in pass 1 (its parity picks the DC buffer)
         auto pass1 = [&]() {
-            if constexpr (DCX) {
-                // bin 0 of this lane's 32 samples in double (the same sum as the four-wave kernel's DCX path); pass 1
-                // is the shorter phase of a half-step, so this rides in its slack.  The tail adds the 16 partial sums
-                // of a frame two half-steps later.
-                const double *wr = Wd + lo * kWdRow;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-                for (int m = 0; m < 16; m += 2) {
-                    a0 = __builtin_fma(wr[2 * m + 0], (double)ep[m][0], a0);
-                    a1 = __builtin_fma(wr[2 * m + 1], (double)ep[m][1], a1);
-                    a2 = __builtin_fma(wr[2 * m + 2], (double)ep[m + 1][0], a2);
-                    a3 = __builtin_fma(wr[2 * m + 3], (double)ep[m + 1][1], a3);
-                }
-                DcT[(gi * 2 + (k_tile & 1)) * (kTile * kDcRow) + fr_id * kDcRow + lo] = (a0 + a1) + (a2 + a3);
-                ++k_tile;
-            }
             // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
             // (the longer of the two phases: it gets the SIMD's issue priority over the partner group's pass 2,
             // whichever of the two waves is older -- measured: 2000 clocks per half-step instead of 2400)
@@ -351,13 +359,13 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         bool have_a = false, have_b = false;
         if (nA > 0) {                                  // prologue: S_A(0) and S_B(0) directly
             fetch_window3(pa.sl, pa.window(), u, fa);
-            park_window3(Sf(0), u, fa);
+            park_window3<DCX>(Sf(0), Rw, u, fa);
             pa.next(s, rag, t.n_cep, out);
             ++ka;
         }
         if (nB > 0) {
             fetch_window3(pb.sl, pb.window(), u, fb);
-            park_window3(Sf(1), u, fb);
+            park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb);
             pb.next(s, rag, t.n_cep, out);
             ++kb;
         }
@@ -381,7 +389,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             // A window is re-parked in the half-step in which its group runs pass 1 on operands it already holds in
             // registers: S_A(h / 2 + 1) at even h, S_B((h + 1) / 2) at odd h; the group reads it in its next pass 2
             if (!(h & 1)) {
-                if (have_a) park_window3(Sf(0), u, fa);
+                if (have_a) park_window3<DCX>(Sf(0), Rw, u, fa);
                 have_a = false;
                 if (ka < nA) {
                     fetch_window3(pa.sl, pa.window(), u, fa);
@@ -390,7 +398,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     have_a = true;
                 }
             } else {
-                if (have_b) park_window3(Sf(1), u, fb);
+                if (have_b) park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb);
                 have_b = false;
                 if (kb < nB) {
                     fetch_window3(pb.sl, pb.window(), u, fb);
@@ -409,7 +417,55 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         float ax[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ax[i] = t.a_extra[(1 * kAextra + i) * 64 + lane];
+        // DCX: bin 0 of a tile's 16 frames as exact integer sums over the raw window (see the header).  A window is
+        // valid for one half-step: R_A(k) during h = 2 k - 1 (tile 0: between the prologue barriers), R_B(k) during 2 k.
+        // (This wave has no global load in flight.  In the parker waves, which have the registers too, every vmcnt the
+        // compiler puts into the chain waits for the window fetch just issued: +1 800 clocks per half-step, measured.)
+        v4i adc[DCX ? kDcBlocks : 1];
+        TileStream<RAGGED> da, db;
+        if constexpr (DCX) {
+#pragma unroll
+            for (int b = 0; b < kDcBlocks; ++b) adc[b] = reinterpret_cast<const v4i *>(t.a_dc_i8)[b * 64 + lane];
+            da.start(s, g, rag, va, gv, t.n_cep, out);
+            db.start(s, g, rag, vb, gv, t.n_cep, out);
+        }
+        auto dc_tile = [&](int gi, int k, TileStream<RAGGED> &dts) {
+            // lane (frame lo, k-group q): 16 bytes = 4 dwords per k-block, 16 dwords apart
+            const int *rp = Rw + gi * kRawWords + (dts.window().shift >> 1) + 85 * lo + 4 * q;
+            v4i acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};       // two chains: an MFMA does not wait for the one before it
+            // the operands of nine (then eight) k-blocks are read in one go: under the workers' LDS traffic a read
+            // takes several hundred clocks, and two in flight at a time made the chain 1 400 clocks long
+            constexpr int kHalf = (kDcBlocks + 1) / 2;
+            v4i x[kHalf];
+#pragma unroll
+            for (int b = 0; b < kHalf; ++b) x[b] = (v4i){rp[16 * b], rp[16 * b + 1], rp[16 * b + 2], rp[16 * b + 3]};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < kHalf; ++b) {
+                if (b & 1) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(adc[b], x[b], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(adc[b], x[b], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = kHalf; b < kDcBlocks; ++b)
+                x[b - kHalf] = (v4i){rp[16 * b], rp[16 * b + 1], rp[16 * b + 2], rp[16 * b + 3]};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = kHalf; b < kDcBlocks; ++b) {
+                if (b & 1) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(adc[b], x[b - kHalf], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(adc[b], x[b - kHalf], acc, 0, 0, 0);
+            }
+            acc += acc2;
+            // rows 4 q + r (digit j = row of the lo bytes, kDcDigits + j of the hi bytes), column = frame lo
+            int *d = DcI + (gi * 2 + (k & 1)) * 256 + lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[(4 * q + r) * 16] = acc[r];
+            dts.next(s, rag, t.n_cep, out);
+        };
         lds_barrier();                                 // the parkers' two prologue barriers
+        if constexpr (DCX) {
+            if (nA > 0) dc_tile(0, 0, da);
+        }
         lds_barrier();
         W12_LOOP_BEGIN
         for (int h = 0; h <= last_h; ++h) {
@@ -434,6 +490,13 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 *reinterpret_cast<f32x4 *>(Q + (2 * 4 + 0) * 256 + lane * 4) = x0 + y0;
                 *reinterpret_cast<f32x4 *>(Q + (2 * 4 + 1) * 256 + lane * 4) = x1 + y1;
             }
+            if constexpr (DCX) {
+                if (h & 1) {
+                    if ((h + 1) / 2 < nA) dc_tile(0, (h + 1) / 2, da);
+                } else {
+                    if (h / 2 < nB) dc_tile(1, h / 2, db);
+                }
+            }
             W12_T1(h);
             lds_barrier();
         }
@@ -450,12 +513,16 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         tb.start(s, g, rag, vb, gv, t.n_cep, out);
         // bin 0's weight in this lane's eight filters (4 q + r of block 0, 16 + 4 q + r of block 1)
         f32x4 wdc0 = zero, wdc1 = zero;
+        double dc_scale = 0.0, dc_bias_lo = 0.0, dc_bias_hi = 0.0;
         if constexpr (DCX) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 wdc0[r] = t.w_dc[4 * q + r];
                 wdc1[r] = t.w_dc[16 + 4 * q + r];
             }
+            dc_scale = t.dc_consts[0];
+            dc_bias_lo = t.dc_consts[1];
+            dc_bias_hi = t.dc_consts[2];
         }
         lds_barrier();
         lds_barrier();
@@ -469,15 +536,26 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 const f32x4 *Q4 = reinterpret_cast<const f32x4 *>(Qt(gi)) + lane;
                 f32x4 m0 = ((Q4[0 * 64] + Q4[2 * 64]) + (Q4[4 * 64] + Q4[6 * 64])) + Q4[8 * 64];
                 f32x4 m1 = ((Q4[1 * 64] + Q4[3 * 64]) + (Q4[5 * 64] + Q4[7 * 64])) + Q4[9 * 64];
-                if constexpr (DCX) {                   // bin 0 of frame lo: the workers' 16 partial sums, in double
-                    const double *dr = DcT + (gi * 2 + (k & 1)) * (kTile * kDcRow) + lo * kDcRow;
-                    double x0 = 0.0, x1 = 0.0;
+                if constexpr (DCX) {                   // bin 0 of frame lo: wave 10's fourteen integer sums, combined in double
+                    // sum_j 128^j (lo_j + 256 hi_j) + 128 sum(C), exactly: digits 0..3 and the low 28 bits of the
+                    // constant stay below 2^52, digits 4..6 (x 2^-28) and its high part below 2^45 -- every FMA is
+                    // exact, and the one rounding is that of the final sum
+                    const int *dr = DcI + (gi * 2 + (k & 1)) * 256 + lo;
+                    double L = dc_bias_lo, H = dc_bias_hi, sc = 1.0;
 #pragma unroll
-                    for (int n2 = 0; n2 < 16; n2 += 2) {
-                        x0 += dr[n2];
-                        x1 += dr[n2 + 1];
+                    for (int j = 0; j < 4; ++j) {
+                        L = __builtin_fma((double)dr[j * 16], sc, L);
+                        L = __builtin_fma((double)dr[(kDcDigits + j) * 16], sc * 256.0, L);
+                        sc *= 128.0;
                     }
-                    x0 += x1;
+                    sc = 1.0;
+#pragma unroll
+                    for (int j = 4; j < kDcDigits; ++j) {
+                        H = __builtin_fma((double)dr[j * 16], sc, H);
+                        H = __builtin_fma((double)dr[(kDcDigits + j) * 16], sc * 256.0, H);
+                        sc *= 128.0;
+                    }
+                    const double x0 = __builtin_fma(H, 268435456.0, L) * dc_scale;
                     const float p0 = (float)(x0 * x0);
                     m0 += wdc0 * p0;
                     m1 += wdc1 * p0;

@@ -135,8 +135,10 @@ if __name__ == "__main__":
         sys.exit(0)
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
-    t0 = time.time(); cases = nfail = 0
+    t0 = time.time(); cases = nfail = 0; t_said = t0
     while time.time() - t0 < budget:
+        if time.time() - t_said > 60:                  # a line a minute: a silent GPU run is taken to be hung
+            t_said = time.time(); print("...", cases, "cases,", nfail, "fails after %.0f s" % (t_said - t0), flush=True)
         seed = seed0 * 10_000_000 + cases
         cases += 1
         try:

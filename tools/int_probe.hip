@@ -6,12 +6,19 @@
 #include <cstdio>
 #include <vector>
 
-enum Op { NONE = 0, ADD, SDWA_ADD, SDWA_SHR, ASHR, DOT2S, MADU64, MUL24, CNDMASK, PERM, PKADD16, PKASHR16, MADI16, ALIGNBIT, BFE, MULLO, SWIZZLE, BFLY, CND64, BFI, CNDDEP, CMPCND };
+enum Op { NONE = 0, ADD, SDWA_ADD, SDWA_SHR, ASHR, DOT2S, MADU64, MUL24, CNDMASK, PERM, PKADD16, PKASHR16, MADI16, ALIGNBIT, BFE, MULLO, SWIZZLE, BFLY, CND64, BFI, CNDDEP, CMPCND, I8MFMA, I8MFMA32 };
 
 template <int OP>
 __device__ __forceinline__ void stream(int iters, int seed, int *sink) {
     if constexpr (OP == NONE) return;
     int q[16]; unsigned long long w[8];
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    v4i acc4[8]; v16i acc16[4]; v4i opa = {seed, 2, 3, 4}, opb = {5, 6, 7, seed};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc4[i] = (v4i){i, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc16[i] = (v16i){i};
 #pragma unroll
     for (int i = 0; i < 16; ++i) q[i] = seed * 77 + i * 12345;
 #pragma unroll
@@ -36,6 +43,8 @@ __device__ __forceinline__ void stream(int iters, int seed, int *sink) {
                 if constexpr (OP == CND64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(q[i]) : "v"(q[j]), "s"(msk));
                 if constexpr (OP == BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(q[i]) : "v"(q[15]), "v"(q[j]));
                 if constexpr (OP == CMPCND) asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(q[i]) : "v"(q[j]), "v"(q[(i + 2) & 15]) : "vcc");
+                if constexpr (OP == I8MFMA) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc4[i & 7]) : "v"(opa), "v"(opb));
+                if constexpr (OP == I8MFMA32) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc16[i & 3]) : "v"(opa), "v"(opb));
                 if constexpr (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(q[j]), "s"(0x07060302));
                 if constexpr (OP == PKADD16) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(q[i]) : "v"(q[j]));
                 if constexpr (OP == PKASHR16) asm volatile("v_pk_ashrrev_i16 %0, 1, %0" : "+v"(q[i]));
@@ -66,7 +75,9 @@ __device__ __forceinline__ void stream(int iters, int seed, int *sink) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += q[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += (int)w[i];
+    for (int i = 0; i < 8; ++i) s += (int)w[i] + acc4[i][0] + acc4[i][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc16[i][0] + acc16[i][15];
     if (s == 123456789) *sink = s;
 }
 
@@ -121,5 +132,9 @@ int main() {
     BOTH(BFE, "v_bfe_i32");
     BOTH(SWIZZLE, "ds_swizzle_b32");
     BOTH(BFLY, "packed butterfly (12)");
+    BOTH(I8MFMA, "v_mfma_i32_16x16x64_i8");
+    BOTH(I8MFMA32, "v_mfma_i32_32x32x32_i8");
+    run<I8MFMA, ADD>("mfma_i8 || v_add_u32", it, sink, cyc);
+    run<I8MFMA, DOT2S>("mfma_i8 || dot2", it, sink, cyc);
     return 0;
 }
