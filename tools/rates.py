@@ -24,8 +24,8 @@ run("same, generic kernel", impl="generic", **base)
 run("float 512 / 32 coefficients", nfft=512, nfilters=32, nceptrums=32)
 run("float 512 @8 kHz (dense sets, 12-wave)", samplerate=8000, **base)
 run("float 512 @22.05 kHz", samplerate=22050, **base)
-run("float 512 @44.1 kHz (dense sets + double DC bin, 12-wave)", samplerate=44100, **base)
-run("float 512 @48 kHz (dense sets + double DC bin, 12-wave)", samplerate=48000, **base)
+run("float 512 @44.1 kHz (dense sets + exact integer DC bin, 12-wave)", samplerate=44100, **base)
+run("float 512 @48 kHz (dense sets + exact integer DC bin, 12-wave)", samplerate=48000, **base)
 run("float 512 / 16 filters (constructor default)", nfft=512, nfilters=16, nceptrums=16)
 run("float 1024/341/40/13 (config 4 kernel)", nfft=1024, nfilters=40, nceptrums=13, power_scale=0)
 run("float 1024/341/40/32", nfft=1024, nfilters=40, nceptrums=32, power_scale=0)
