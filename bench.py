@@ -202,9 +202,10 @@ def roofline(frames, bytes_per_frame, kernel_ms, kernel_name, note_extra=""):
         "traffic_unit": "bytes per launch (algorithmic: %d)" % (frames * bytes_per_frame),
         "traffic_source": src,
         "kernel_ms": round(kernel_ms, 4),
-        "note": "algorithmic bytes = frames x %d B / HIP-event kernel time; the path is fp32-VALU/LDS bound "
+        "note": "algorithmic bytes = frames x %d B / HIP-event kernel time; the path is %s bound "
                 "(DESIGN.md), so this fraction is reported as asked, not as the binding limit%s"
-                % (bytes_per_frame, note_extra),
+                % (bytes_per_frame, "integer-VALU (a 16-bit datapath emulated bit for bit)" if "fixed" in kernel_name
+                   else "fp32-VALU/LDS", note_extra),
     }
     if traffic is None and stale:
         r["traffic_dropped"] = "%s was collected on other kernel sources (stamp mismatch)" % stale
