@@ -311,8 +311,9 @@ int build_tables(mfcc_hip_handle *h) {
     size_t o_fu = 0;
     if (h->fused_ok) o_fu = a.put(fused_blob);
     std::vector<char> f1k_blob;
+    int f1k_sched = 0;
     h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
-                    mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob);
+                    mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_sched);
     size_t o_f1k = 0;
     if (h->fused1k_ok) o_f1k = a.put(f1k_blob);
 
@@ -354,7 +355,7 @@ int build_tables(mfcc_hip_handle *h) {
         const char *e = std::getenv("MFCC_HIP_FUSED512");
         h->fused_w12 = h->fused_ok && !(e && std::strcmp(e, "w4") == 0);
     }
-    if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, h->f1k);
+    if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, f1k_sched, h->f1k);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
         h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];

@@ -253,20 +253,45 @@ def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
     assert e_max <= TOL and e_l2 <= TOL
 
 
-@pytest.mark.parametrize("sr", [8000, 22050, 44100])
+@pytest.mark.parametrize("sr", [8000, 11025, 22050, 32000, 44100, 48000])
 def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
-    """The banded MFMA lists of the fused kernels are the band structure of the mel matrix at 16 kHz; their
-    table builders check every non-zero weight is covered.  Otherwise the 512 kernel switches to its dense
-    instantiation (all 32 (k2, block) pairs, any rate) and the 1024 kernel leaves the set to the generic one."""
+    """The banded MFMA lists of the fused kernels are the band structure of the mel matrix at ONE sample rate; their
+    table builders check every non-zero weight is covered.  The 512 kernel switches to its dense instantiation (all 32
+    (k2, block) pairs, any rate).  The 1024 kernel has one schedule per rate whose 17 + 18 operand sets fit its
+    registers (8, 11.025, 16, 22.05 kHz); 32 kHz needs 19 and 44.1 / 48 kHz put weight on the DC bin: generic kernel."""
     x = mf.synth_pcm(30000, seed=2)
     for nfft, nmel in ((512, 32), (1024, 40)):
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
             got = m.process(x)
             if nfft == 512:
                 assert m.kernel_name().startswith("mfcc_fused512")
+            else:
+                assert m.kernel_name() == ("mfcc_fused1024_kernel" if sr <= 22050 else "mfcc_float_generic_kernel"), sr
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
+
+
+@pytest.mark.parametrize("sr", [8000, 11025, 22050])
+def test_fused1024_schedules_of_other_rates_vs_generic_and_oracle(mfcc_amd, sr):
+    """Each per-rate schedule of the 1024 kernel: several channels at odd alignments, 32 coefficients, STREAM framing,
+    against the float64 oracle and against the generic kernel on the device."""
+    import torch
+    nch, n = 3, 341 * 50 + 1024 + 77
+    flat = np.zeros(5 + (n + 3) * nch + 64, np.int16)
+    for c in range(nch):
+        flat[5 + c * (n + 3): 5 + c * (n + 3) + n] = mf.synth_pcm(n, seed=500 + sr % 97 + c)
+    view = torch.as_strided(torch.from_numpy(flat).cuda(), (nch, n), (n + 3, 1), storage_offset=5)
+    kw = dict(nfft=1024, nfilters=40, nceptrums=32, samplerate=sr, power_scale=0, pad_mode="stream")
+    with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
+        assert a.kernel_name() == "mfcc_fused1024_kernel"
+        ga, gb = a.process(view).cpu().numpy(), b.process(view).cpu().numpy()
+    for c in range(nch):
+        ref = mf.mfcc_float_ref(flat[5 + c * (n + 3): 5 + c * (n + 3) + n], n_cep=32, nfft=1024, hop=341, n_mel=40,
+                                sample_rate=sr, power_scale=1024.0, pad_mode="stream")
+        for g in (ga[c], gb[c]):
+            e_max, e_l2 = _err(g, ref)
+            assert e_max <= TOL and e_l2 <= TOL, (sr, c)
 
 
 def test_constructor_defaults_16_filters_run_on_the_fused_kernel(mfcc_amd, wav_pcm):
