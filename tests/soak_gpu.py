@@ -4,7 +4,7 @@ Random channel counts, lengths, channel strides and base offsets (all alignment 
 framing mode, n_cep 1..32 and six signal kinds (Gaussian at three levels, full-scale uniform, Gaussian
 with a stretch of silence, DC, full-scale square, pure sine).  Fixed contract: the fused fixed-point
 kernel against oracle/mfcc_fixed.py, bit for bit.  Float contract: the fused 512 (random sample rates, 16-filter
-banks) and 1024 (its four per-rate schedules) kernels AND the generic kernel, each against the float64 oracle on the first channel (1e-4 of the
+banks) and 1024 (its five per-rate schedules) kernels AND the generic kernel, each against the float64 oracle on the first channel (1e-4 of the
 largest coefficient, identical -inf / NaN pattern) and against each other on all channels (5e-5).  DC / square /
 sine inputs have mel bands at the fp32 noise floor where fp32 FFTs legitimately differ from float64 after the log
 (DESIGN.md section 1): they are reported, not counted, unless FUZZ_STRICT is set.  No sample rate is masked (round 1
@@ -93,7 +93,7 @@ def one_case(seed):
                 break
         return fails
     nmel = (16 if rng.random() < 0.25 else 32) if cfg == "f512" else 40
-    sr = int(rng.choice([16000, 16000, 8000, 22050, 44100, 48000] if cfg == "f512" else [16000, 16000, 8000, 11025, 22050]))
+    sr = int(rng.choice([16000, 16000, 8000, 22050, 44100, 48000] if cfg == "f512" else [16000, 16000, 8000, 11025, 22050, 32000]))
     kw = dict(nfft=nfft, nfilters=nmel, nceptrums=min(ncep, nmel), pad_mode=pad, samplerate=sr,
               power_scale=512.0 if cfg == "f512" else 0)
     tag += " nmel %d sr %d" % (nmel, sr)

@@ -257,8 +257,8 @@ def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
 def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
     """The banded MFMA lists of the fused kernels are the band structure of the mel matrix at ONE sample rate; their
     table builders check every non-zero weight is covered.  The 512 kernel switches to its dense instantiation (all 32
-    (k2, block) pairs, any rate).  The 1024 kernel has one schedule per rate whose 17 + 18 operand sets fit its
-    registers (8, 11.025, 16, 22.05 kHz); 32 kHz needs 19 and 44.1 / 48 kHz put weight on the DC bin: generic kernel."""
+    (k2, block) pairs, any rate).  The 1024 kernel has one schedule per rate (8, 11.025, 16, 22.05, 32 kHz: 17..19
+    operand sets per wave fit its registers); 44.1 / 48 kHz put weight on the DC bin: generic kernel."""
     x = mf.synth_pcm(30000, seed=2)
     for nfft, nmel in ((512, 32), (1024, 40)):
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
@@ -266,13 +266,13 @@ def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
             if nfft == 512:
                 assert m.kernel_name().startswith("mfcc_fused512")
             else:
-                assert m.kernel_name() == ("mfcc_fused1024_kernel" if sr <= 22050 else "mfcc_float_generic_kernel"), sr
+                assert m.kernel_name() == ("mfcc_fused1024_kernel" if sr <= 32000 else "mfcc_float_generic_kernel"), sr
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
 
 
-@pytest.mark.parametrize("sr", [8000, 11025, 22050])
+@pytest.mark.parametrize("sr", [8000, 11025, 22050, 32000])
 def test_fused1024_schedules_of_other_rates_vs_generic_and_oracle(mfcc_amd, sr):
     """Each per-rate schedule of the 1024 kernel: several channels at odd alignments, 32 coefficients, STREAM framing,
     against the float64 oracle and against the generic kernel on the device."""
