@@ -66,10 +66,12 @@ struct Fetch3 {
     i32x4 v[kParkPieces];
     int p[kParkPieces];          // dword in front of v[k]: its high half is the piece's predecessor sample
     int odd;                     // DCX: the window's shift is odd (the frames' sample -1 lies in a low half as fetched)
+    int shift;                   // RAGGED: published for the workers
 };
 
 __device__ __forceinline__ void fetch_window3(const mfcc_k::StreamDesc &s, const Window &w, int u, Fetch3 &f) {
     f.odd = w.shift & 1;
+    f.shift = w.shift;
     if (w.inside) {
         const i32x4 *g = reinterpret_cast<const i32x4 *>(w.ptr - w.shift);
         const int *g32 = reinterpret_cast<const int *>(g);
@@ -96,7 +98,8 @@ __device__ __forceinline__ void fetch_window3(const mfcc_k::StreamDesc &s, const
 // fetched when the shift is odd, (2 d - 1, 2 d) when it is even: either way sample -1 of frame f is the LOW half of
 // dword (shift >> 1) + 85 f.  Stored with the lo bytes' top bit flipped (lo - 128 as a signed byte).
 template <bool RAW>
-__device__ __forceinline__ void park_window3(float *Sf, int *R, int u, const Fetch3 &f) {
+__device__ __forceinline__ void park_window3(float *Sf, int *R, int u, const Fetch3 &f, int *shift_slot = nullptr) {
+    if (shift_slot && u == 0) *shift_slot = f.shift;
 #pragma unroll
     for (int k = 0; k < kParkPieces; ++k) {
         preemph8(f.p[k], f.v[k], Sf + 8 * (k * kParkers + u));
@@ -123,8 +126,8 @@ __device__ __forceinline__ Cursor cursor_of(const mfcc_k::StreamDesc &s, const L
 }
 
 // ---- ragged corpora without a packing copy: the tiles of utterances of different lengths, straight out of the
-// caller's buffer.  Per utterance one record, per tile one (utterance, tile-in-utterance) pair; a wave fetches both with
-// scalar loads when it moves to its next tile.  Every utterance is an independent stream that starts from reset
+// caller's buffer.  The host writes one record per utterance, a small kernel expands them into one 32-byte record per
+// tile, and a wave fetches its next tile's record with one scalar load, a tile ahead of its use.  Every utterance is an independent stream that starts from reset
 // (history 0) and is zero-padded at its end, exactly like a channel of the plain call -- so the frames are the same
 // bits as one call per utterance.
 struct RaggedChan {
@@ -134,14 +137,24 @@ struct RaggedChan {
     int t_hi;                // tiles 1 .. t_hi have their whole window inside the utterance
     int tile0;               // index of its first tile in the tile map
 };
+// what a wave needs to know about a tile, in one 32-byte record (one s_load_dwordx8): expanded from the utterance
+// records by ragged_tile_map_kernel
+struct RaggedTile {
+    long long pcm_off;       // first sample of the tile's utterance, relative to StreamDesc::pcm
+    long long out_row;       // first output row (frame) of that utterance
+    int n_samples, frames;   // of the utterance
+    int t_hi;                // tiles 1 .. t_hi of the utterance have their whole window inside it
+    int t_in;                // the tile's index inside its utterance
+};
 struct RaggedTables {
-    const int2 *tile_map;    // [n_tiles] (utterance, tile in utterance)
-    const RaggedChan *chans; // [n_utterances]
+    const RaggedTile *tiles; // [n_tiles]
     int n_tiles;
 };
 
 // One role's walk over one group's tiles (virtual workgroup v0, stride gv): where the tile's samples are, how its
 // window lies in its stream, where its rows go.  RAGGED = false is the arithmetic cursor of the plain call.
+// RAGGED: the record of the NEXT tile of the walk is fetched while the current one is worked on (a scalar load that
+// is waited for only a tile later; fetched on demand it cost every wave an L2 round trip per tile: 3.24 -> see DESIGN 6b).
 template <bool RAGGED>
 struct TileStream {
     Cursor c;
@@ -150,17 +163,22 @@ struct TileStream {
     float *outp;
     unsigned v;
     int gv;
-    __device__ __forceinline__ void load(const mfcc_k::StreamDesc &s, const RaggedTables &r, int n_cep, float *out) {
-        if ((int)v < r.n_tiles) {
-            const int2 m = r.tile_map[v];
-            const RaggedChan ch = r.chans[m.x];
-            c.ch = 0;
-            c.t_in = m.y;
-            c.ptr = s.pcm + ch.pcm_off + (long long)m.y * kTileHop;
-            sl.n_samples = ch.n_samples;
-            sl.frames_per_ch = ch.frames;
-            gl.t_hi = ch.t_hi;
-            outp = out + ch.out_row * n_cep;
+    RaggedTile nx;           // record of tile v + gv
+    __device__ __forceinline__ void adopt(const mfcc_k::StreamDesc &s, const RaggedTile &r, int n_cep, float *out) {
+        c.ch = 0;
+        c.t_in = r.t_in;
+        c.ptr = s.pcm + r.pcm_off + (long long)r.t_in * kTileHop;
+        sl.n_samples = r.n_samples;
+        sl.frames_per_ch = r.frames;
+        gl.t_hi = r.t_hi;
+        outp = out + r.out_row * n_cep;
+    }
+    // called right before a barrier: the wait that the next LDS access brings (lgkmcnt counts scalar loads too) then
+    // falls into the barrier wait instead of into the work
+    __device__ __forceinline__ void prefetch(const RaggedTables &r) {
+        if constexpr (RAGGED) {
+            const unsigned vn = v + (unsigned)gv;
+            if ((int)vn < r.n_tiles) nx = r.tiles[vn];
         }
     }
     __device__ __forceinline__ void start(const mfcc_k::StreamDesc &s, const LaunchGeom &g, const RaggedTables &r,
@@ -176,7 +194,9 @@ struct TileStream {
             c.ch = 0;
             c.t_in = 0;
             c.ptr = s.pcm;
-            load(s, r, n_cep, out);
+            nx = RaggedTile{0, 0, 0, 0, -1, 0};
+            if ((int)v < r.n_tiles) adopt(s, r.tiles[v], n_cep, out);
+            prefetch(r);
         } else {
             c = cursor_of(s, g, v0);
         }
@@ -184,7 +204,7 @@ struct TileStream {
     __device__ __forceinline__ void next(const mfcc_k::StreamDesc &s, const RaggedTables &r, int n_cep, float *out) {
         if constexpr (RAGGED) {
             v += (unsigned)gv;
-            load(s, r, n_cep, out);
+            if ((int)v < r.n_tiles) adopt(s, nx, n_cep, out);      // the caller prefetches the one after it (see prefetch)
         } else {
             advance(c, gl);
         }
@@ -219,7 +239,10 @@ template <bool DENSE, bool RAGGED, bool DCX>
 __global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, RaggedTables rag, float *__restrict__ out) {
     constexpr int kSets = SetsBf<DENSE>::N;
-    __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords + (DCX ? kDcLdsWords : 0)];
+    __shared__ __attribute__((aligned(16))) float lds[kW12LdsWords + (DCX ? kDcLdsWords : 0) + (RAGGED ? 4 : 0)];
+    // RAGGED: the shift of the window that lies in S_A / S_B, published by the parkers next to the window itself -- the
+    // eight worker waves then need no per-tile record at all (they used to fetch one each: an L2 round trip per tile)
+    int *const Shw = reinterpret_cast<int *>(lds + kW12LdsWords + (DCX ? kDcLdsWords : 0));
     int *const Rw = reinterpret_cast<int *>(lds + kW12LdsWords);           // DCX: raw windows [group][kRawWords]
     int *const DcI = Rw + 2 * kRawWords;                                    // DCX: [group][tile parity][16 rows][16 frames]
     const int tid = threadIdx.x;
@@ -267,8 +290,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         float *const T = Tt(gi), *const V = Vt(gi), *const Q = Qt(gi), *const S = Sf(gi);
         const int lane_slot = fr_id * kHop + lo;
         const int n_mine = gi ? nB : nA;
-        TileStream<RAGGED> cur;
-        cur.start(s, g, rag, gi ? vb : va, gv, t.n_cep, out);
+        TileStream<false> cur;                         // the plain call's arithmetic cursor (RAGGED: unused, see Shw)
+        if constexpr (!RAGGED) cur.start(s, g, rag, gi ? vb : va, gv, t.n_cep, out);
 
         lds_barrier();                                 // the parkers' prologue: S_A(0) and S_B(0) are in LDS
         // The pass-1 operands of a tile are read out of its window ONE half-step early, in the middle of the same
@@ -276,7 +299,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         // on registers instead of waiting for 32 LDS reads while the partner group does the same for its T columns.
         v2f ep[16];
         auto load_ep = [&]() {
-            const float *sp = S + lane_slot + cur.window().shift;
+            const float *sp = S + lane_slot + (RAGGED ? Shw[gi] : cur.window().shift);
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) ep[n1 >> 1][n1 & 1] = sp[16 * n1];
         };
@@ -310,7 +333,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             }
             PowerBf pb;
             split_power(pw, pb);
-            cur.next(s, rag, t.n_cep, out);
+            if constexpr (!RAGGED) cur.next(s, rag, t.n_cep, out);
             load_ep();           // the next tile's operands fly during the MFMAs (after the last tile they are never used)
             f32x4 acc[kSets];
 #pragma unroll
@@ -359,28 +382,34 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         bool have_a = false, have_b = false;
         if (nA > 0) {                                  // prologue: S_A(0) and S_B(0) directly
             fetch_window3(pa.sl, pa.window(), u, fa);
-            park_window3<DCX>(Sf(0), Rw, u, fa);
+            park_window3<DCX>(Sf(0), Rw, u, fa, RAGGED ? Shw + 0 : nullptr);
             pa.next(s, rag, t.n_cep, out);
+            pa.prefetch(rag);
             ++ka;
         }
         if (nB > 0) {
             fetch_window3(pb.sl, pb.window(), u, fb);
-            park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb);
+            park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb, RAGGED ? Shw + 1 : nullptr);
             pb.next(s, rag, t.n_cep, out);
+            pb.prefetch(rag);
             ++kb;
         }
         if (ka < nA) {                                 // S_A(1): parked at h = 0
             fetch_window3(pa.sl, pa.window(), u, fa);
             pa.next(s, rag, t.n_cep, out);
+            pa.prefetch(rag);
             ++ka;
             have_a = true;
         }
         if (kb < nB) {                                 // S_B(1): parked at h = 1
             fetch_window3(pb.sl, pb.window(), u, fb);
             pb.next(s, rag, t.n_cep, out);
+            pb.prefetch(rag);
             ++kb;
             have_b = true;
         }
+        pa.prefetch(rag);
+        pb.prefetch(rag);
         lds_barrier();                                 // S_A(0), S_B(0) are parked: the workers fetch tile 0's operands
         lds_barrier();                                 // ... and hold them in registers: h = 0 may start
         W12_LOOP_BEGIN
@@ -389,7 +418,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             // A window is re-parked in the half-step in which its group runs pass 1 on operands it already holds in
             // registers: S_A(h / 2 + 1) at even h, S_B((h + 1) / 2) at odd h; the group reads it in its next pass 2
             if (!(h & 1)) {
-                if (have_a) park_window3<DCX>(Sf(0), Rw, u, fa);
+                if (have_a) park_window3<DCX>(Sf(0), Rw, u, fa, RAGGED ? Shw + 0 : nullptr);
                 have_a = false;
                 if (ka < nA) {
                     fetch_window3(pa.sl, pa.window(), u, fa);
@@ -398,7 +427,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     have_a = true;
                 }
             } else {
-                if (have_b) park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb);
+                if (have_b) park_window3<DCX>(Sf(1), Rw + kRawWords, u, fb, RAGGED ? Shw + 1 : nullptr);
                 have_b = false;
                 if (kb < nB) {
                     fetch_window3(pb.sl, pb.window(), u, fb);
@@ -407,6 +436,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     have_b = true;
                 }
             }
+            pa.prefetch(rag);
+            pb.prefetch(rag);
             W12_T1(h);
             lds_barrier();
         }
@@ -465,6 +496,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         lds_barrier();                                 // the parkers' two prologue barriers
         if constexpr (DCX) {
             if (nA > 0) dc_tile(0, 0, da);
+            da.prefetch(rag);
         }
         lds_barrier();
         W12_LOOP_BEGIN
@@ -496,6 +528,8 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 } else {
                     if (h / 2 < nB) dc_tile(1, h / 2, db);
                 }
+                da.prefetch(rag);
+                db.prefetch(rag);
             }
             W12_T1(h);
             lds_barrier();
@@ -573,10 +607,16 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     d0 = MFCC_MFMA(ax[r], l0[r], d0);
                     d1 = MFCC_MFMA(ax[4 + r], l1[r], d1);
                 }
-                TileStream<RAGGED> &c = gi ? tb : ta;
-                dct_store(c.sl, t, l0, l1, d0, d1, ax, c.c, lo, q, lane_off, c.outp);
-                c.next(s, rag, t.n_cep, out);
+                // (not `TileStream &c = gi ? tb : ta`: a reference picked at run time puts both walks into scratch)
+                auto finish = [&](TileStream<RAGGED> &c) {
+                    dct_store(c.sl, t, l0, l1, d0, d1, ax, c.c, lo, q, lane_off, c.outp);
+                    c.next(s, rag, t.n_cep, out);
+                };
+                if (gi) finish(tb);
+                else finish(ta);
             }
+            ta.prefetch(rag);
+            tb.prefetch(rag);
             W12_T1(h);
             lds_barrier();
         }
@@ -609,7 +649,7 @@ inline bool launch(const mfcc_k::StreamDesc &s, const FusedTables &t, bool dense
     if (g.t_lo < 0) g.t_lo = 0;
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
-    const RaggedTables none = {nullptr, nullptr, 0};
+    const RaggedTables none = {nullptr, 0};
     if (dcx)
         hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, false, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, none, out);
     else if (dense)
@@ -627,14 +667,16 @@ inline int ragged_t_hi(long long n_samples, long long tiles) {
     return (int)(hi < tiles ? hi : tiles);
 }
 
-__global__ void ragged_tile_map_kernel(const RaggedChan *__restrict__ chans, int n_chan, int2 *__restrict__ map) {
+__global__ void ragged_tile_map_kernel(const RaggedChan *__restrict__ chans, int n_chan, RaggedTile *__restrict__ tiles) {
     for (int u = blockIdx.x; u < n_chan; u += gridDim.x) {
-        const int tiles = (chans[u].frames + kTile - 1) / kTile, t0 = chans[u].tile0;
-        for (int k = threadIdx.x; k < tiles; k += blockDim.x) map[t0 + k] = make_int2(u, k);
+        const RaggedChan ch = chans[u];
+        const int n = (ch.frames + kTile - 1) / kTile;
+        for (int k = threadIdx.x; k < n; k += blockDim.x)
+            tiles[ch.tile0 + k] = RaggedTile{ch.pcm_off, ch.out_row, ch.n_samples, ch.frames, ch.t_hi, k};
     }
 }
 
-inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n_chan, int2 *d_map, int n_tiles,
+inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n_chan, RaggedTile *d_map, int n_tiles,
                           const FusedTables &t, bool dense, float *out, int n_cu, hipStream_t stream) {
     if (n_tiles <= 0) return false;
     const bool dcx = t.win_dc != nullptr;
@@ -655,7 +697,7 @@ inline bool launch_ragged(const int16_t *d_pcm, const RaggedChan *d_chans, int n
     g.n_ch = 0;
     g.t_lo = 1;
     g.t_hi = -1;
-    const RaggedTables r = {d_map, d_chans, n_tiles};
+    const RaggedTables r = {d_map, n_tiles};
     if (dcx)
         hipLaunchKernelGGL((mfcc_fused512_w12_kernel<true, true, true>), dim3((unsigned)wgs), dim3(64 * kW12Waves), 0, stream, s, t, g, r, out);
     else if (dense)

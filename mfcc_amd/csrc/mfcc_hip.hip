@@ -619,14 +619,14 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
         if (n_tiles < (1ll << 30)) {
             const size_t chan_bytes = n_utt * sizeof(mfcc_fused12::RaggedChan);
             const size_t map_off = (chan_bytes + 255) & ~size_t(255);
-            rc = ensure(h, &h->d_in, &h->d_in_bytes, map_off + size_t(n_tiles) * sizeof(int2) + 64);
+            rc = ensure(h, &h->d_in, &h->d_in_bytes, map_off + size_t(n_tiles) * sizeof(mfcc_fused12::RaggedTile) + 64);
             if (rc) return rc;
             if ((rc = scratch_acquire(h))) return rc;
             HIP_TRY(h, hipMemcpyAsync(h->d_in, rc_host, chan_bytes, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipEventRecord(pd->copied, h->stream));
             pd->in_flight = true;
             auto *d_chans = static_cast<const mfcc_fused12::RaggedChan *>(h->d_in);
-            int2 *d_map = reinterpret_cast<int2 *>(static_cast<char *>(h->d_in) + map_off);
+            auto *d_map = reinterpret_cast<mfcc_fused12::RaggedTile *>(static_cast<char *>(h->d_in) + map_off);
             if (mfcc_fused12::launch_ragged(d_pcm, d_chans, (int)n_utt, d_map, (int)n_tiles, h->fu, h->fused_dense,
                                             reinterpret_cast<float *>(d_out), h->n_cu, h->stream)) {
                 HIP_TRY(h, hipGetLastError());

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, mfcc_amd
 n_utt, n = 10_000, 160_000
 flat = (torch.randn(n_utt * n, device="cuda") * 3000).clamp_(-32768, 32767).to(torch.int16)
-with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13) as m:
+with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, samplerate=int(os.environ.get("RAG_SR", "16000"))) as m:
     for name, lens in (("uniform", [n] * n_utt), ("ragged", [n - 997 * (u % 5) for u in range(n_utt)])):
         # ragged: utterances packed back to back (no gaps) in a fresh buffer
         offs = np.zeros(n_utt + 1, dtype=np.uint64); offs[1:] = np.cumsum(lens, dtype=np.uint64)
