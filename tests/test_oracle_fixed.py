@@ -91,6 +91,34 @@ def test_bounded_against_float_model(wav_pcm):
     assert (v["log"][~nz] == 0).all()
 
 
+def test_whole_fixed_chain_tracks_the_pinned_float_chain_on_the_wav(wav_pcm):
+    """End to end, against the oracle that IS pinned (the notebook's float chain): undo both DCTs on the reference's
+    own wav and compare the log-mel values band by band over the louder half of the frames.  In the bands that are wide
+    enough not to care that the RTL's filters sit one bin later (A.6) -- 14..31 -- the fixed chain's log2 values are
+    the float chain's plus a constant (the two scalings): correlation >= 0.98, slope 1 +- 0.1, residual spread below
+    half a log2 unit.  A wrong stage order, scale or twiddle sign in the restatement would not survive this; the narrow
+    low bands (one to three bins) genuinely differ between the two designs and are left out.  Not a bit-level pin."""
+    fx = mx.mfcc_fixed_ref(wav_pcm, nceptrums=32, pad_mode="notebook").astype(np.float64)
+    fl = mf.mfcc_float_ref(wav_pcm, n_cep=32)
+    assert fx.shape == fl.shape == (1046, 32)
+    n = np.arange(32)
+    k = np.arange(32)[:, None]
+    cosm = np.cos(np.pi * k * (2 * n + 1) / 64)
+    ortho = cosm * np.sqrt(np.where(k == 0, 1.0, 2.0) / 32)                # the notebook's DCT-II (cell 38)
+    lm_float = fl @ ortho                                                  # orthonormal: the inverse is the transpose
+    lm_fixed = np.linalg.solve(cosm / 64, fx.T).T / 2048.0                 # dct_stream.py:23-44 undone, Q4.11 -> log2
+    loud = fl[:, 0] > np.median(fl[:, 0])
+    for band in range(14, 32):
+        a, b = lm_fixed[loud, band], lm_float[loud, band]
+        slope = np.polyfit(b, a, 1)[0]
+        assert np.corrcoef(a, b)[0, 1] >= 0.98, band
+        assert 0.9 <= slope <= 1.1, (band, slope)
+        assert np.std(a - b) < 0.55, band
+    # the constant between the two is the same in every such band to within the filters' different areas
+    off = np.array([np.mean(lm_fixed[loud, b] - lm_float[loud, b]) for b in range(14, 32)])
+    assert off.max() - off.min() < 1.0
+
+
 def test_filterbank_impulse_response_is_shifted_by_one_bin():
     """Appendix A.6: every RTL filter sits one bin later than the notebook's."""
     W = mf.mel_filterbank(512, 32, 16000)
