@@ -115,3 +115,34 @@ def test_four_wave_form_of_the_fused_512_kernel_still_agrees(mfcc_amd, wav_pcm, 
     assert w4.shape == w12.shape == ref.shape
     assert np.abs(w4 - w12).max() / scale < 2e-5
     assert np.abs(w4 - ref).max() / scale <= TOL and np.abs(w12 - ref).max() / scale <= TOL
+
+
+@pytest.mark.gpu
+def test_handles_and_sessions_give_their_device_memory_back(mfcc_amd):
+    """create / use / destroy in a loop -- handles of every kernel family, ragged batches, streaming sessions: the
+    device's free memory (hipMemGetInfo, which also sees the library's own hipMalloc) ends where it started."""
+    import torch
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-3000, 3000, 60000).astype(np.int16)
+    utts = [pcm[:n] for n in (700, 5000, 12345, 60000)]
+
+    def one_round():
+        for kw in (dict(nfft=512, nfilters=32, nceptrums=13), dict(nfft=512, nfilters=32, nceptrums=13, samplerate=48000),
+                   dict(nfft=1024, nfilters=40, nceptrums=13, power_scale=0), dict(nfft=256, nfilters=16, nceptrums=8)):
+            with mfcc_amd.MFCC(pad_mode="stream", **kw) as m:
+                m.process(pcm)
+                m.process_batch(utts)
+                if kw["nfft"] != 1024:
+                    m.process_fixed(pcm)
+                    m.process_batch(utts, fixed=True)
+                with m.stream() as st:
+                    st.push(pcm[:4096]); st.push(pcm[4096:9000]); st.flush()
+
+    one_round()                                    # first use: the runtime's own one-time allocations
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        one_round()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)
