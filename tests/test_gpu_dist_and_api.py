@@ -146,3 +146,32 @@ def test_handles_and_sessions_give_their_device_memory_back(mfcc_amd):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+@pytest.mark.gpu
+def test_distinct_handles_on_distinct_host_threads_are_independent(mfcc_amd):
+    """include/mfcc_hip.h: a handle is not thread-safe, distinct handles are independent.  Four host threads, each
+    with its own handle (own stream, own scratch) and its own input, both contracts, many calls in flight at once:
+    every result equals the single-threaded one, bit for bit."""
+    import threading
+    rng = np.random.default_rng(17)
+    inputs = [rng.integers(-8000, 8000, 20000 + 1111 * i).astype(np.int16) for i in range(4)]
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=16, pad_mode="stream") as m:
+        want = [(m.process(x), m.process_fixed(x)) for x in inputs]
+    errors = []
+
+    def work(i):
+        try:
+            with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=16, pad_mode="stream") as h:
+                for _ in range(40):
+                    if not np.array_equal(h.process(inputs[i]), want[i][0], equal_nan=True):
+                        errors.append(("float", i))
+                    if not np.array_equal(h.process_fixed(inputs[i]), want[i][1]):
+                        errors.append(("fixed", i))
+        except Exception as e:           # noqa: BLE001 -- reported below, from the main thread
+            errors.append((repr(e), i))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors[:4]
