@@ -7,7 +7,7 @@ lib = mfcc_amd.load_library()
 lib.mfcc_hip_debug_read_stamps12.argtypes = [C.c_void_p]
 nch = 64
 pcm = (torch.randn((nch, 9_600_000), device="cuda") * 3000).clamp_(-32768, 32767).to(torch.int16)
-m = mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, samplerate=int(os.environ.get("STAMP_SR", "16000")))
+m = mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=int(os.environ.get("STAMP_NCEP", "13")), samplerate=int(os.environ.get("STAMP_SR", "16000")))
 out = m.process(pcm); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 48)()
 lib.mfcc_hip_debug_read_stamps12(buf)
