@@ -6,7 +6,10 @@
 // fx_mel) -> Turner log2 Q4.11 (log.py:33-102) -> 128-point fixed FFT as DCT (dct_stream.py:23-44)
 // -> first n_cep int16 (misc/discard.py).  Other parameter sets take mfcc_fixed_kernel.
 //
-// One frame per wave, four waves per workgroup, nothing shared between waves but read-only tables.
+// One frame per wave, four waves per workgroup, nothing shared between waves but read-only tables.  The tables a
+// lane needs once per frame or less (round-3 twiddles, filterbank weights, DCT twiddles) are staged in LDS per
+// workgroup instead of held in registers: 79 VGPRs, six waves per SIMD.  The grid is many times what is resident
+// (96 workgroups per CU): see launch().
 // Every butterfly is the RTL's own (same products, same bias, same shifts, same wraps); what changes
 // is where the data lives:
 //
@@ -282,11 +285,15 @@ struct Geom {
     int step_ch;
 };
 
-__global__ __launch_bounds__(64 * kWaves)
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t xbuf[kWaves][kXWords];     // gather / transposes / power
     __shared__ __attribute__((aligned(16))) uint32_t rawbuf[kWaves][kRawWords];
     __shared__ int melv[kWaves][2][kMel];                       // filterbank sums of a pair of frames, then their logs
+    // per-lane tables, [entry][lane]: conflict-free to read, fetched where they are used
+    __shared__ uint32_t mwl[kMelChunk * 64];                    // filterbank weights of the lane's piece
+    __shared__ uint32_t twdl[13 * 64];                          // DCT twiddles and indices (lanes 32..63 = 0..31)
+    __shared__ uint32_t tw3l[14 * 64];                          // round-3 twiddles
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -297,20 +304,16 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     int curve[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) curve[m] = t.curve8[lane * 8 + m];
-    uint32_t tw2[14], tw3[14], twd[13];
+    for (int i = tid; i < kMelChunk * 64; i += 64 * kWaves) mwl[i] = t.mel_wl[i];
+    for (int i = tid; i < 13 * 64; i += 64 * kWaves) twdl[i] = t.tw_dct[(i & 31) * 16 + (i >> 6)];
+    for (int i = tid; i < 14 * 64; i += 64 * kWaves) tw3l[i] = t.tw_r3[(i & 63) * 14 + (i >> 6)];
+    uint32_t tw2[14];
 #pragma unroll
-    for (int i = 0; i < 14; ++i) {
-        tw2[i] = t.tw_r2[(lane & 7) * 14 + i];
-        tw3[i] = t.tw_r3[lane * 14 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 13; ++i) twd[i] = t.tw_dct[(lane & 31) * 16 + i];
+    for (int i = 0; i < 14; ++i) tw2[i] = t.tw_r2[(lane & 7) * 14 + i];
     int slot = 0;                                   // frames waiting for the paired log2 + DCT pass
     long long row[2] = {0, 0};
-    const int4 ml = t.mel_lane[lane];               // this lane's piece of a filterbank row, and its weights
-    uint32_t mw[kMelChunk];
-#pragma unroll
-    for (int u = 0; u < kMelChunk; ++u) mw[u] = t.mel_wl[u * 64 + lane];
+    const int4 ml = t.mel_lane[lane];               // this lane's piece of a filterbank row
+    __syncthreads();
     const int br6 = (int)(__brev((unsigned)lane) >> 26);
     
     // first frame of this wave; then strides of (all waves of the grid)
@@ -434,7 +437,12 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
             for (int r = 0; r < 8; ++r) x[r] = X[72 * r + lane];
             wave_fence();
         }
-        round3<true>(x, tw3);
+        {
+            uint32_t tw3[14];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) tw3[i] = tw3l[i * 64 + lane];
+            round3<true>(x, tw3);
+        }
 
         // ---- power (pow2.py:32,64) of bins lane + 64 c, c = 0..3, to LDS for the filterbank
 #pragma unroll
@@ -452,7 +460,7 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
 #pragma unroll
             for (int u = 0; u < kMelChunk; u += 2) {        // bins past the piece: weight 0
                 if (u < t.mel_chunk)
-                    acc += (unsigned long long)xp[u] * mw[u] + (unsigned long long)xp[u + 1] * mw[u + 1];
+                    acc += (unsigned long long)xp[u] * mwl[u * 64 + lane] + (unsigned long long)xp[u + 1] * mwl[(u + 1) * 64 + lane];
             }
 #pragma unroll
             for (int d = 1; d <= kMelSpanMax; d <<= 1) {
@@ -468,6 +476,9 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
         wave_fence();
 
         if (slot == 2 || !more) {
+            uint32_t twd[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) twd[i] = twdl[i * 64 + lane];
             // ---- log2 (log.py:33-102) of both frames' sums: half h of the wave takes frame h
             const int h = lane >> 5, l5 = lane & 31;
             int *mv = melv[wave][h];
@@ -516,7 +527,13 @@ inline const char *kernel_name() { return "mfcc_fixed512_kernel"; }
 inline void launch(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, int n_cu, hipStream_t stream) {
     const long long total = s.total_frames;
     long long blocks = (total + kWaves - 1) / kWaves;
-    const long long cap = (long long)n_cu * 4;          // 16 waves per CU
+    // Many more workgroups than are resident (6 per CU by registers and LDS).  Measured on config 3, kernel ms: the
+    // exactly resident grid 3.57, 2 x 3.32, 4 x 3.19, 8 x 3.11, 16 x 3.08, 32 x 3.10, 64 x 3.17 -- and with round 2's
+    // register-resident tables (4 waves per SIMD) 3.78 at 1 x, 3.20 at 16 x.  A grid that is merely full leaves slots
+    // empty: workgroups are not placed evenly over the CUs, and one that waits for a slot runs after the others; with
+    // a deep queue every slot is refilled the moment it frees up.  (The float kernels place ONE workgroup per CU, 256
+    // of them: nothing to gain there, measured.)
+    const long long cap = (long long)n_cu * 96;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     Geom g;
