@@ -212,15 +212,24 @@ def roofline(frames, bytes_per_frame, kernel_ms, kernel_name, note_extra=""):
     return r, valu, src
 
 
-def valu_roofline(torch, dev, frames, kernel_ms, valu_per_frame, src):
-    # the binding limit: every VALU wave-instruction holds a SIMD for >= 4 clocks
+# fixed-point kernel: a third of its vector instructions (static count over the loop body) are plain add / shift / and
+# ops that hold the pipe 2.4 clocks, the rest (dot2, SDWA, mul24, bfe, perm, v_mad_u64_u32 ...) 3.2 or more
+# (tools/int_probe.hip, profiles/r02_int_probe.txt): 0.33 x 2.4 + 0.67 x 3.2
+FIXED_PIPE_CLK = 2.94
+
+
+def valu_roofline(torch, dev, frames, kernel_ms, valu_per_frame, src, fixed=False):
+    # the binding limit: every VALU wave-instruction holds a SIMD for 4 clocks (round 1's definition,
+    # kept for the float path next to alu_roofline); the integer kernel is priced at its measured instruction mix
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    ceiling = n_cu * 4 * 2.4e9 / (valu_per_frame * 4.0)
+    clk = FIXED_PIPE_CLK if fixed else 4.0
+    ceiling = n_cu * 4 * 2.4e9 / (valu_per_frame * clk)
     rate = frames / (kernel_ms * 1e-3)
     return {"bound": "valu", "achieved": round(rate, 1), "peak": round(ceiling, 1), "unit": "frames/s per GPU",
             "frac": round(rate / ceiling, 4),
-            "note": "peak = CUs x 4 SIMDs x 2.4 GHz / (%.1f VALU wave-instructions per frame x 4 clocks), "
-                    "instruction count from %s" % (valu_per_frame, src)}
+            "note": "peak = CUs x 4 SIMDs x 2.4 GHz / (%.1f VALU wave-instructions per frame x %s clocks%s), "
+                    "instruction count from %s" % (valu_per_frame, clk, " of pipe: a third plain ops at 2.4, the rest at "
+                                                   "3.2, tools/int_probe.hip" if fixed else "", src)}
 
 
 # Measured on MI355X with tools/alu_probe.hip (profiles/r02_alu_probe.txt), two waves per SIMD: a packed fp32 op
@@ -346,7 +355,7 @@ def bench_config2(cx, args):
             "cpu_baseline": None,
         }
         if valu:
-            line["valu_roofline"] = valu_roofline(torch, dev, frames, kernel_ms, valu, src)
+            line["valu_roofline"] = valu_roofline(torch, dev, frames, kernel_ms, valu, src, fixed=args.fixed)
             if PROFILE["mfma_per_frame"] and PROFILE["mfma_clk_per_frame"] and kname.startswith("mfcc_fused512"):
                 line["alu_roofline"] = alu_roofline(torch, dev, frames, kernel_ms, valu, PROFILE["mfma_per_frame"],
                                                     PROFILE["mfma_clk_per_frame"], src)
@@ -446,7 +455,7 @@ def bench_config5(cx, args, steps, warmup, with_cpu):
             "cpu_baseline": None,
         }
         if valu:
-            res["valu_roofline"] = valu_roofline(torch, dev, frames_local, kernel_ms, valu, src)
+            res["valu_roofline"] = valu_roofline(torch, dev, frames_local, kernel_ms, valu, src, fixed=args.fixed)
         if with_cpu:
             k = min(len(mine), 256)
             rows = out.view(len(mine), per, NCEP)
