@@ -19,7 +19,7 @@
 //    integer, it never overflows 33 bits: SURVEY.md A.4);
 //  * the 9 stages run as three rounds of three stages on 8 register-resident values per lane (index
 //    bits 0-2, 3-5, 6-8), with two transposes through LDS instead of nine stage round trips; the
-//    twiddles of a round depend on the lane only and live in registers for the whole kernel;
+//    twiddles of a round depend on the lane only (round 2's stay in registers, round 3's come from LDS);
 //  * the bit-reversed load is free: lane l computes pre-emphasis and window of the samples
 //    bitrev6(l) + 64 bitrev3(r) themselves, straight from the staged raw samples;
 //  * the last stage computes only the outputs that are read out (bins 0..255);
@@ -300,7 +300,7 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     uint32_t *X = xbuf[wave];
     uint32_t *Rb = rawbuf[wave];
 
-    // read-only tables in registers for the whole kernel
+    // read-only tables: the window curve and round 2's twiddles in registers, the rest staged in LDS here
     int curve[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) curve[m] = t.curve8[lane * 8 + m];
