@@ -1,5 +1,6 @@
 // Fused fixed-point kernel for gfx950 (MI355X): the RTL arithmetic of mfcc/core for its own
-// configuration -- MFCC(width=16, nfft=512, nfilters=32), mfcc/core/mfcc.py:20-88 -- bit for bit:
+// configuration -- MFCC(width=16, nfft=512, nfilters=32), mfcc/core/mfcc.py:20-88, and for the constructor's default
+// of 16 filters (mfcc.py:20-21) -- bit for bit:
 // pre-emphasis (preemph.py:24) -> window curve (window.py:84) -> 512-point radix-2 DIT FFT with Q14
 // twiddles, +8191 >>14 and a >>1 per stage with 16-bit wrap (misc/fft.py:93-96,140-192) ->
 // (re^2+im^2)>>2 (pow2.py:32,64) -> filterbank in closed form (filterbank.py:88-142, tables.hpp:
@@ -29,8 +30,8 @@
 //  * in the DCT's 128-point FFT every even input is 0, so the lower half of the bit-reversed array
 //    stays 0 until the last stage: stages 0-5 are a 64-point FFT of the upper half and the last stage
 //    is one rotation per output;
-//  * log2 and that 64-point FFT run once per PAIR of frames: a frame's 32 filterbank sums wait in LDS
-//    for the next frame's, then each half of the wave takes one frame -- one log2 per lane, and the FFT
+//  * log2 and that 64-point FFT run once per PAIR of frames (16 filters: a 32-point FFT, once per FOUR frames): a
+//    frame's filterbank sums wait in LDS for the next frame's, then each half (quarter) of the wave takes one frame -- one log2 per lane, and the FFT
 //    with two values per lane: stage 0 pairs them in the lane, each later stage swaps one value with the
 //    lane 2^(st-1) away (ds_swizzle) so that the butterfly is again inside the lane.
 #pragma once
@@ -46,7 +47,7 @@
 
 namespace mfcc_fixed512 {
 
-constexpr int kNfft = 512, kMel = 32, kWaves = 4;
+constexpr int kNfft = 512, kMel = 32, kWaves = 4;   // kMel: the larger of the two filter counts (32, 16)
 constexpr int kXWords = 512 + 64;        // transpose buffer: index i lives at i + 8 (i >> 6)
 constexpr int kRawWords = 65 * 4;        // raw-sample staging: 65 aligned 16-byte pieces cover a frame + history
 
@@ -57,15 +58,17 @@ struct Tables {
     const int *curve8;        // [64 lanes][8]   window curve of sample bitrev6(lane) + 64 bitrev3(r)
     const uint32_t *tw_r2;    // [8 lo3][7][2]   round-2 twiddles (stages 3, 4, 5) as dot2 operand pairs
     const uint32_t *tw_r3;    // [64 lanes][7][2] round-3 twiddles (stages 6, 7, 8)
-    const uint32_t *tw_dct;   // [32 lanes][16] DCT FFT, two values per lane: stages 1-5 (pairs), last-stage rotations, indices
+    const uint32_t *tw_dct;   // [n_mel lanes][16] DCT FFT, two values per lane: stages 1.. (pairs), last-stage rotations, indices
     uint32_t tw64a, tw64b, tw192a, tw192b;   // stage-2 twiddles T[64], T[192]
     const int4 *mel_lane;     // [64 lanes] piece of a filter row: first bin, -, (filter | head << 8), last lane of the filter
     const uint32_t *mel_wl;   // [chunk][64 lanes] the piece's weights (x 2^-30), 0 past its end
     int mel_chunk, mel_span;  // bins per piece (kMelChunk or less); lanes of the widest filter - 1
-    int mel_shift, n_cep;
+    int mel_shift, n_cep, n_mel;
 };
 
-inline bool supported(int nfft, int n_mel, int n_cep) { return nfft == kNfft && n_mel == kMel && n_cep >= 1 && n_cep <= kMel; }
+inline bool supported(int nfft, int n_mel, int n_cep) {
+    return nfft == kNfft && (n_mel == 32 || n_mel == 16) && n_cep >= 1 && n_cep <= n_mel;
+}
 
 // dot2 operand pair of a twiddle: A = (twr, -twi) gives s1, B = (twi, twr) gives s2
 inline void tw_pair(int re, int im, uint32_t &a, uint32_t &b) {
@@ -74,7 +77,7 @@ inline void tw_pair(int re, int im, uint32_t &a, uint32_t &b) {
 }
 
 // host: tables in the order the kernel consumes them.  blob layout: curve8 | tw_r2 | tw_r3 | tw_dct
-inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
+inline bool build_tables(int n_mel, std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
     using namespace mfcc_tables;
     std::vector<int> cv = fx_window_curve(kNfft);
     std::vector<int> re, im;
@@ -89,7 +92,7 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
         for (int k = 0; k < 6; ++k) b6 |= ((l >> k) & 1) << (5 - k);
         for (int r = 0; r < 8; ++r) c8[l * 8 + r] = cv[b6 + 64 * (((r & 1) << 2) | (r & 2) | (r >> 2))];
     }
-    std::vector<uint32_t> r2(8 * 7 * 2), r3(64 * 7 * 2), rd(32 * 16);
+    std::vector<uint32_t> r2(8 * 7 * 2), r3(64 * 7 * 2), rd(32 * 16, 0u);
     auto put_tw = [&](std::vector<uint32_t> &v, size_t at, const std::vector<int> &R, const std::vector<int> &I, int ta) {
         tw_pair(R[ta], I[ta], v[at], v[at + 1]);
     };
@@ -108,39 +111,41 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
     }
     tw_pair(re[64], im[64], tw_s2[0], tw_s2[1]);
     tw_pair(re[192], im[192], tw_s2[2], tw_s2[3]);
-    // DCT: 128-point FFT (fft.py:310-331 again), upper half only.  Element e of that half (array index 64 + e) starts
-    // as u[bitrev6(e)], u[m] = x[m] (m < 32), x[63 - m] (m >= 32).  Lane l starts with elements 2l, 2l + 1; before
-    // stage st >= 1 the lanes l and l ^ 2^(st-1) swap one value (the lower lane its second, the upper its first), so
-    // that every lane again holds a butterfly's x0 and x1.  Stage s of element e: j = e mod 2^s, ta = (j << (6-s)) & 63.
+    // DCT: the (4 n_mel)-point FFT (fft.py:310-331 again), upper half only: H = 2 n_mel elements, LH = log2 H stages
+    // inside the half.  Element e of that half (array index H + e) starts as u[bitrev_LH(e)], u[m] = x[m] (m < n_mel),
+    // x[H - 1 - m] (m >= n_mel).  Lane l (of n_mel) starts with elements 2l, 2l + 1; before stage st >= 1 the lanes l
+    // and l ^ 2^(st-1) swap one value (the lower lane its second, the upper its first), so that every lane again holds a
+    // butterfly's x0 and x1.  Stage s of element e: j = e mod 2^s, ta = (j << (LH - s)) & (H - 1).
     // Per lane: [2(st-1)], [2(st-1)+1] operand pair of stage st; [10], [11] last-stage rotation (ta = e) of the two
     // final elements; [12] = load index 0 | load index 1 << 8 | final element 0 << 16 | final element 1 << 24.
     std::vector<int> dr, di;
-    fx_twiddles(4 * kMel, dr, di);                    // 64 entries
+    fx_twiddles(4 * n_mel, dr, di);                   // H entries
     {
+        const int H = 2 * n_mel, LH = n_mel == 32 ? 6 : 5;
         int el[32][2];
-        auto br6 = [](int e) { int b = 0; for (int k = 0; k < 6; ++k) b |= ((e >> k) & 1) << (5 - k); return b; };
-        for (int l = 0; l < 32; ++l) {
+        auto brv = [&](int e) { int b = 0; for (int k = 0; k < LH; ++k) b |= ((e >> k) & 1) << (LH - 1 - k); return b; };
+        for (int l = 0; l < n_mel; ++l) {
             el[l][0] = 2 * l; el[l][1] = 2 * l + 1;
-            const int m0 = br6(2 * l), m1 = br6(2 * l + 1);
-            rd[l * 16 + 12] = uint32_t(m0 < 32 ? m0 : 63 - m0) | uint32_t(m1 < 32 ? m1 : 63 - m1) << 8;
+            const int m0 = brv(2 * l), m1 = brv(2 * l + 1);
+            rd[l * 16 + 12] = uint32_t(m0 < n_mel ? m0 : H - 1 - m0) | uint32_t(m1 < n_mel ? m1 : H - 1 - m1) << 8;
         }
         if (dr[0] != 16384 || di[0] != 0) return false;       // stage 0 is mult-free
-        for (int st = 1; st < 6; ++st) {
+        for (int st = 1; st < LH; ++st) {
             const int mask = 1 << (st - 1);
             int nx[32][2];
-            for (int l = 0; l < 32; ++l) {
+            for (int l = 0; l < n_mel; ++l) {
                 const int pl = l ^ mask;
                 if (!(l & mask)) { nx[l][0] = el[l][0]; nx[l][1] = el[pl][0]; }
                 else             { nx[l][0] = el[pl][1]; nx[l][1] = el[l][1]; }
                 if ((nx[l][0] & (1 << st)) || nx[l][1] != (nx[l][0] | (1 << st))) return false;
-                put_tw(rd, size_t(l) * 16 + 2 * (st - 1), dr, di, ((nx[l][0] & ((1 << st) - 1)) << (6 - st)) & 63);
+                put_tw(rd, size_t(l) * 16 + 2 * (st - 1), dr, di, ((nx[l][0] & ((1 << st) - 1)) << (LH - st)) & (H - 1));
             }
-            std::memcpy(el, nx, sizeof(el));
+            for (int l = 0; l < n_mel; ++l) { el[l][0] = nx[l][0]; el[l][1] = nx[l][1]; }
         }
-        for (int l = 0; l < 32; ++l) {
+        for (int l = 0; l < n_mel; ++l) {
             uint32_t a, b;
-            tw_pair(dr[el[l][0] & 63], di[el[l][0] & 63], a, b); rd[l * 16 + 10] = a;
-            tw_pair(dr[el[l][1] & 63], di[el[l][1] & 63], a, b); rd[l * 16 + 11] = a;
+            tw_pair(dr[el[l][0] & (H - 1)], di[el[l][0] & (H - 1)], a, b); rd[l * 16 + 10] = a;
+            tw_pair(dr[el[l][1] & (H - 1)], di[el[l][1] & (H - 1)], a, b); rd[l * 16 + 11] = a;
             rd[l * 16 + 12] |= uint32_t(el[l][0]) << 16 | uint32_t(el[l][1]) << 24;
         }
     }
@@ -160,7 +165,7 @@ inline bool build_tables(std::vector<char> &blob, uint32_t (&tw_s2)[4]) {
 // host: the filterbank rows (tables.hpp: pack_rows) cut into pieces of `chunk` bins, one per lane -- the smallest
 // chunk that fits 64 lanes.  lanes: 4 ints per lane, see Tables::mel_lane; wl: the weights, [kMelChunk][64].
 constexpr int kMelChunk = 12;            // bins per lane the kernel is unrolled for (10 are needed at 16 kHz)
-constexpr int kMelSpanMax = 7;           // three doubling steps of the segmented reduction
+constexpr int kMelSpanMax = 15;          // four doubling steps of the segmented reduction (16 filters: up to 11 lanes per filter)
 inline bool build_mel_lanes(const std::vector<int> &start, const std::vector<int> &count, const std::vector<int> &off,
                             const std::vector<uint32_t> &w, std::vector<int> &lanes, std::vector<uint32_t> &wl,
                             int &chunk, int &span) {
@@ -285,11 +290,14 @@ struct Geom {
     int step_ch;
 };
 
+template <int MEL>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t xbuf[kWaves][kXWords];     // gather / transposes / power
     __shared__ __attribute__((aligned(16))) uint32_t rawbuf[kWaves][kRawWords];
-    __shared__ int melv[kWaves][2][kMel];                       // filterbank sums of a pair of frames, then their logs
+    constexpr int kPass = 64 / MEL;                             // frames per log2 + DCT pass: 2 (32 filters) or 4 (16)
+    __shared__ int melv[kWaves][64];                            // [frame of the pass][filter]: filterbank sums, then their logs
+    __shared__ long long rowsh[kWaves][4];                      // output rows of the frames of the pass
     // per-lane tables, [entry][lane]: conflict-free to read, fetched where they are used
     __shared__ uint32_t mwl[kMelChunk * 64];                    // filterbank weights of the lane's piece
     __shared__ uint32_t twdl[13 * 64];                          // DCT twiddles and indices (lanes 32..63 = 0..31)
@@ -305,13 +313,12 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
 #pragma unroll
     for (int m = 0; m < 8; ++m) curve[m] = t.curve8[lane * 8 + m];
     for (int i = tid; i < kMelChunk * 64; i += 64 * kWaves) mwl[i] = t.mel_wl[i];
-    for (int i = tid; i < 13 * 64; i += 64 * kWaves) twdl[i] = t.tw_dct[(i & 31) * 16 + (i >> 6)];
+    for (int i = tid; i < 13 * 64; i += 64 * kWaves) twdl[i] = t.tw_dct[(i & (MEL - 1)) * 16 + (i >> 6)];
     for (int i = tid; i < 14 * 64; i += 64 * kWaves) tw3l[i] = t.tw_r3[(i & 63) * 14 + (i >> 6)];
     uint32_t tw2[14];
 #pragma unroll
     for (int i = 0; i < 14; ++i) tw2[i] = t.tw_r2[(lane & 7) * 14 + i];
-    int slot = 0;                                   // frames waiting for the paired log2 + DCT pass
-    long long row[2] = {0, 0};
+    int slot = 0;                                   // frames waiting for the shared log2 + DCT pass
     const int4 ml = t.mel_lane[lane];               // this lane's piece of a filterbank row
     __syncthreads();
     const int br6 = (int)(__brev((unsigned)lane) >> 26);
@@ -469,19 +476,19 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
                     if (lane + d <= ml.w) acc += ((unsigned long long)hi2 << 32) | lo2;
                 }
             }
-            if (ml.z >> 8) melv[wave][slot][ml.z & 0xff] = (int)((unsigned)(acc >> t.mel_shift) & 0xFFFFu);
+            if (ml.z >> 8) melv[wave][slot * MEL + (ml.z & 0xff)] = (int)((unsigned)(acc >> t.mel_shift) & 0xFFFFu);
         }
-        row[slot] = (long long)c.ch * g.frames_per_ch + c.f;
+        if (lane == 0) rowsh[wave][slot] = (long long)c.ch * g.frames_per_ch + c.f;
         ++slot;
         wave_fence();
 
-        if (slot == 2 || !more) {
+        if (slot == kPass || !more) {
             uint32_t twd[13];
 #pragma unroll
             for (int i = 0; i < 13; ++i) twd[i] = twdl[i * 64 + lane];
-            // ---- log2 (log.py:33-102) of both frames' sums: half h of the wave takes frame h
-            const int h = lane >> 5, l5 = lane & 31;
-            int *mv = melv[wave][h];
+            // ---- log2 (log.py:33-102) of all the pass's sums: part h of the wave takes frame h
+            const int h = lane / MEL, l5 = lane & (MEL - 1);
+            int *mv = melv[wave] + h * MEL;
             {
                 const unsigned v = (unsigned)mv[l5];
                 const unsigned v1 = v ? v : 1u;
@@ -498,17 +505,18 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
                 mv[l5] = (int)(o & 0x7FFFu);
             }
             wave_fence();
-            // ---- DCT (dct_stream.py:23-33): 128-point FFT of y[2n+1] = y[127-2n] = x[n]; see build_tables
+            // ---- DCT (dct_stream.py:23-33): (4 MEL)-point FFT of y[2n+1] = y[4 MEL - 1 - 2n] = x[n]; see build_tables
             {
                 uint32_t s0 = (uint32_t)mv[twd[12] & 0xff], s1 = (uint32_t)mv[(twd[12] >> 8) & 0xff];
                 bfly_one(s0, s1);
                 dct_stage<1>(s0, s1, twd, lane); dct_stage<2>(s0, s1, twd, lane); dct_stage<3>(s0, s1, twd, lane);
-                dct_stage<4>(s0, s1, twd, lane); dct_stage<5>(s0, s1, twd, lane);
+                dct_stage<4>(s0, s1, twd, lane);
+                if constexpr (MEL == 32) dct_stage<5>(s0, s1, twd, lane);
                 // last stage: x0 = 0 (lower half), x1 = the element, twiddle index = its number; Re of y0 only
                 const int a0 = rot14(s0, twd[10]), a1 = rot14(s1, twd[11]);
                 const int e0 = (twd[12] >> 16) & 0xff, e1 = twd[12] >> 24;
                 if (h < slot) {
-                    int16_t *o = out + (h ? row[1] : row[0]) * t.n_cep;
+                    int16_t *o = out + rowsh[wave][h] * t.n_cep;
                     if (e0 < t.n_cep) o[e0] = (int16_t)(a0 >> 1);
                     if (e1 < t.n_cep) o[e1] = (int16_t)(a1 >> 1);
                 }
@@ -542,7 +550,10 @@ inline void launch(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, i
     const long long stride = blocks * kWaves;
     g.step_ch = (int)(stride / s.frames_per_ch);
     g.step_f = stride % s.frames_per_ch;
-    hipLaunchKernelGGL(mfcc_fixed512_kernel, dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    if (t.n_mel == 16)
+        hipLaunchKernelGGL(mfcc_fixed512_kernel<16>, dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    else
+        hipLaunchKernelGGL(mfcc_fixed512_kernel<32>, dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
 }
 
 }  // namespace mfcc_fixed512

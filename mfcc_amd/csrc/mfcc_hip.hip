@@ -286,7 +286,7 @@ int build_tables(mfcc_hip_handle *h) {
     std::vector<char> x5_blob;
     uint32_t x5_tw[4] = {0, 0, 0, 0};
     h->fixed512_ok = h->fixed_ok && mfcc_fixed512::supported(r.nfft, r.n_mel, r.n_cep) && x5_lanes_ok &&
-                     mfcc_fixed512::build_tables(x5_blob, x5_tw);
+                     mfcc_fixed512::build_tables(r.n_mel, x5_blob, x5_tw);
     size_t o_x5 = 0, o_x5l = 0, o_x5w = 0;
     if (h->fixed512_ok) {
         o_x5 = a.put(x5_blob);
@@ -365,6 +365,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->x5.mel_wl = reinterpret_cast<const uint32_t *>(b + o_x5w);
         h->x5.mel_shift = fm.shift;
         h->x5.n_cep = r.n_cep;
+        h->x5.n_mel = r.n_mel;
     }
     return MFCC_HIP_SUCCESS;
 }

@@ -440,6 +440,23 @@ def test_fixed_fused_kernel_other_sample_rates(mfcc_amd):
     assert ran >= 4
 
 
+@pytest.mark.parametrize("pad", ["stream", "notebook"])
+def test_fixed_fused_kernel_with_the_constructor_default_of_16_filters(mfcc_amd, pad):
+    """MFCC(nfft=512) with the constructor's 16 filters (mfcc.py:20-21): the fused fixed-point kernel's 16-filter
+    instantiation -- a 64-point DCT FFT, log2 + DCT once per FOUR frames -- bit for bit, for every number of frames
+    modulo four (the last pass of a wave is partly filled), several channels, full-scale inputs, n_cep 1..16."""
+    rng = np.random.default_rng(23)
+    for n_extra, ncep in ((0, 16), (170, 13), (341, 1), (511, 16), (3000, 7)):
+        n = 512 + 170 * 9 + n_extra
+        pcm = np.stack([mf.synth_pcm(n, seed=int(rng.integers(1 << 30))), rng.integers(-32768, 32768, n).astype(np.int16),
+                        np.where(np.arange(n) % 7 < 3, 32767, -32768).astype(np.int16)])
+        ref = mx.mfcc_fixed_ref(pcm, nfilters=16, nceptrums=ncep, pad_mode=pad)
+        with mfcc_amd.MFCC(nfft=512, nfilters=16, nceptrums=ncep, pad_mode=pad) as m:
+            assert m.kernel_name(fixed=True) == "mfcc_fixed512_kernel"
+            got = m.process_fixed(pcm)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (n_extra, ncep, pad)
+
+
 def test_fixed_filterbanks_the_rtl_cannot_stream_are_refused(mfcc_amd):
     """Filter points too dense for the streaming filterbank (filterbank.py:22-34,88-142): the RTL would emit fewer
     than n_mel values per frame (the oracle asserts on exactly these sets) -- UNSUPPORTED, never a made-up result."""
