@@ -257,23 +257,79 @@ __device__ __forceinline__ void dct_stage(uint32_t &s0, uint32_t &s1, const uint
     bfly(s0, s1, twd[2 * (ST - 1)], twd[2 * (ST - 1) + 1]);
 }
 
-struct FrameCursor {
+// One utterance of a ragged corpus (mfcc_hip_process_ragged_*): an independent stream that starts from reset and is
+// zero-padded at its end, exactly like a channel of the plain call.  Only utterances with frames > 0 get a record.
+struct RaggedRec {
+    long long pcm_off;       // first sample, relative to StreamDesc::pcm
+    long long out_row;       // first output row (frame) of the utterance == frames of all utterances before it
+    int n_samples, frames;
+    int pad0, pad1;
+};
+
+struct Geom {
+    long long frames_per_ch;          // plain
+    int n_ch;                         // plain: channels; ragged: utterances with frames
+    long long step_f;                 // plain: frames per stride of all waves, modulo frames_per_ch
+    int step_ch;
+    int chunk;                        // ragged: consecutive frames per wave
+    const RaggedRec *recs;            // nullptr: the plain multi-channel call
+};
+
+// the plain call's cursor, exactly as round 2 measured it (a shared cursor type for both walks compiled 2.6 % slower
+// on config 3 -- the same instruction counts, a different schedule -- so the two walks keep their own few lines)
+struct StridedCursor {
     int ch;
     long long f;
 };
+struct FrameGeom;
+__device__ __forceinline__ FrameGeom geom_of_strided(const mfcc_k::StreamDesc &s, const StridedCursor &c);
 
+typedef const long long __attribute__((address_space(4))) ConstLL;
+__device__ __forceinline__ const ConstLL *rec_ptr(const RaggedRec *recs, int u) {
+    return reinterpret_cast<const ConstLL *>(reinterpret_cast<uintptr_t>(recs + u));
+}
+
+// A wave's position: the stream (channel / utterance) it is in and the frame there.  Kept small: the kernel holds two of
+// them (this frame, the next one) in scalar registers, and a cursor that carried the stream's constants along spilled.
+struct FrameCursor {
+    int u, f;                // f < 2^31: a channel that fills the device's memory has < 2^30 frames
+    const int16_t *base;     // the stream's first sample
+    long long out_row;       // output row of the stream's frame 0
+};
+// what is the same for every frame of a stream (for every frame of the plain call)
+struct StreamConst {
+    long long n_samples;
+    int frames, halo;
+};
+
+template <bool RUNS>
+__device__ __forceinline__ void enter_stream(const mfcc_k::StreamDesc &s, const Geom &g, FrameCursor &c, StreamConst &k) {
+    if (c.u >= g.n_ch) return;
+    if constexpr (RUNS) {
+        // read through the constant address space: the records are written before the launch and never by the kernel, and
+        // only so does the compiler fetch them with scalar loads (as plain global memory it issued vector loads plus
+        // v_readfirstlane and spilled for them)
+        const ConstLL *r = rec_ptr(g.recs, c.u);
+        c.base = s.pcm + r[0];
+        c.out_row = r[1];
+        const long long nf = r[2];                  // n_samples | frames << 32
+        k.n_samples = (int)(nf & 0xffffffffll);
+        k.frames = (int)(nf >> 32);
+        k.halo = 0;
+    }
+}
 // Where a frame's samples are: p = the history sample n0 - 1, mis = samples between the 16-byte
 // boundary below p and p.  fast: the 65 aligned pieces from that boundary lie inside the channel, so the
 // frame can be fetched with one 16-byte load per lane (+1) -- otherwise (stream start without history,
 // zero-padded tail) it is read sample by sample with the stream's edge rules.
 struct FrameGeom {
-    const int16_t *base;
+    const int16_t *base;     // the stream's first sample
     long long n0;
     int mis;
     bool fast;
 };
 
-__device__ __forceinline__ FrameGeom geom_of(const mfcc_k::StreamDesc &s, const FrameCursor &c) {
+__device__ __forceinline__ FrameGeom geom_of_strided(const mfcc_k::StreamDesc &s, const StridedCursor &c) {
     FrameGeom q;
     q.base = s.pcm + (long long)c.ch * s.ch_stride;
     q.n0 = c.f * (long long)s.hop;
@@ -283,14 +339,21 @@ __device__ __forceinline__ FrameGeom geom_of(const mfcc_k::StreamDesc &s, const 
     return q;
 }
 
-struct Geom {
-    long long frames_per_ch;
-    int n_ch;
-    long long step_f;     // frames per stride of all waves, modulo frames_per_ch
-    int step_ch;
-};
+__device__ __forceinline__ FrameGeom geom_of(const int16_t *base, const FrameCursor &c, const StreamConst &k, int hop) {
+    FrameGeom q;
+    q.base = base;
+    q.n0 = c.f * (long long)hop;
+    q.mis = (int)((reinterpret_cast<uintptr_t>(base + q.n0 - 1) & 15) >> 1);
+    const long long lo = q.n0 - 1 - q.mis;
+    q.fast = lo >= -(long long)k.halo && lo + 65 * 8 <= k.n_samples;
+    return q;
+}
 
-template <int MEL>
+// RUNS = false, the plain call: wave w takes the frames w, w + W, w + 2 W ... (W = all waves of the grid) -- at any
+// moment the resident waves work on neighbouring frames.  RUNS = true, a ragged corpus: wave w takes `chunk` CONSECUTIVE
+// frames, so that moving on is ++f with a rare step into the next utterance (a strided walk would have to search the
+// utterance of every frame).  Measured on config 3: runs 3.17 ms, strides 3.09 -- hence both.
+template <int MEL, bool RUNS>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t xbuf[kWaves][kXWords];     // gather / transposes / power
@@ -323,11 +386,32 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     __syncthreads();
     const int br6 = (int)(__brev((unsigned)lane) >> 26);
     
-    // first frame of this wave; then strides of (all waves of the grid)
     const long long wid = (long long)blockIdx.x * kWaves + wave;
-    FrameCursor c;
-    c.ch = (int)(wid / g.frames_per_ch);
-    c.f = wid - (long long)c.ch * g.frames_per_ch;
+    // RUNS: this wave's run of consecutive frames; plain: its first frame, then strides of all waves of the grid
+    FrameCursor c = {};
+    StreamConst kc = {0, 0, 0};
+    StridedCursor sc = {0, 0};
+    int left = 0;
+    if constexpr (RUNS) {
+        const long long first_frame = wid * g.chunk;
+        left = first_frame >= s.total_frames ? 0 : (int)(s.total_frames - first_frame < g.chunk ? s.total_frames - first_frame : g.chunk);
+        if (left > 0) {                                 // the utterance that holds the frame: out_row <= first_frame
+            int lo_u = 0, hi_u = g.n_ch - 1;
+            while (lo_u < hi_u) {
+                const int mid = (lo_u + hi_u + 1) >> 1;
+                if (rec_ptr(g.recs, mid)[1] <= first_frame) lo_u = mid;
+                else hi_u = mid - 1;
+            }
+            c.u = lo_u;
+            enter_stream<RUNS>(s, g, c, kc);
+            c.f = (int)(first_frame - c.out_row);
+        } else {
+            c.u = g.n_ch;
+        }
+    } else {
+        sc.ch = (int)(wid / g.frames_per_ch);
+        sc.f = wid - (long long)sc.ch * g.frames_per_ch;
+    }
 
     // the next frame's samples are fetched one frame ahead: 16 bytes per lane, lane 63 also takes piece 64
     // piece 64 is fetched by lane 63 through an index the compiler cannot see through: a provably uniform
@@ -337,21 +421,43 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     asm volatile("" : "+v"(lane_op));
     // the next frame's samples are fetched one frame ahead: 16 bytes per lane, lane 63 also takes piece 64
     uint4 raw = make_uint4(0, 0, 0, 0), raw64 = raw;
-    FrameGeom q = geom_of(s, c);
-    if (c.ch < g.n_ch && q.fast) {
+    FrameGeom q;
+    if constexpr (RUNS) q = geom_of(c.base, c, kc, s.hop);
+    else q = geom_of_strided(s, sc);
+    if ((RUNS ? c.u < g.n_ch : sc.ch < g.n_ch) && q.fast) {
         const uint4 *src = reinterpret_cast<const uint4 *>(q.base + q.n0 - 1 - q.mis);
         raw = src[lane];
         if (lane == 63) raw64 = src[lane_op + 1];
     }
     i16_alias *const R16 = reinterpret_cast<i16_alias *>(Rb);
 
-    while (c.ch < g.n_ch) {
-        FrameCursor nc = c;
-        nc.f += g.step_f;
-        nc.ch += g.step_ch;
-        if (nc.f >= g.frames_per_ch) {
-            nc.f -= g.frames_per_ch;
-            ++nc.ch;
+    while (RUNS ? c.u < g.n_ch : sc.ch < g.n_ch) {
+        FrameCursor nc;
+        StreamConst kn;                                 // RUNS: the next frame's utterance (another one now and then)
+        StridedCursor snc;
+        bool more;
+        if constexpr (RUNS) {
+            nc = c;
+            kn = kc;
+            if (--left > 0) {
+                if (++nc.f == kc.frames) {
+                    nc.f = 0;
+                    ++nc.u;
+                    enter_stream<RUNS>(s, g, nc, kn);
+                }
+            } else {
+                nc.u = g.n_ch;
+            }
+            more = nc.u < g.n_ch;
+        } else {
+            snc = sc;
+            snc.f += g.step_f;
+            snc.ch += g.step_ch;
+            if (snc.f >= g.frames_per_ch) {
+                snc.f -= g.frames_per_ch;
+                ++snc.ch;
+            }
+            more = snc.ch < g.n_ch;
         }
         // ---- this frame's samples n0 - 1 .. n0 + 511 into the LDS staging buffer, sample n0 - 1 at slot `first`
         int first;
@@ -361,13 +467,21 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
             first = q.mis;
         } else {
             // stream start without history / zero-padded tail: sample by sample with the stream's edge rules
-            for (int k = lane; k < kNfft + 1; k += 64) R16[k] = (int16_t)mfcc_k::sample_at_i(s, q.base, q.n0 - 1 + k);
+            if constexpr (RUNS) {
+                mfcc_k::StreamDesc sl = s;              // the edge rules of sample_at_i on the utterance's numbers
+                sl.n_samples = kc.n_samples;
+                sl.halo = kc.halo;
+                for (int k = lane; k < kNfft + 1; k += 64) R16[k] = (int16_t)mfcc_k::sample_at_i(sl, q.base, q.n0 - 1 + k);
+            } else {
+                for (int k = lane; k < kNfft + 1; k += 64) R16[k] = (int16_t)mfcc_k::sample_at_i(s, q.base, q.n0 - 1 + k);
+            }
             first = 0;
         }
         wave_fence();
         // ---- the next frame's samples start their way from HBM
-        const bool more = nc.ch < g.n_ch;
-        FrameGeom qn = geom_of(s, nc);
+        FrameGeom qn;
+        if constexpr (RUNS) qn = geom_of(nc.base, nc, kn, s.hop);
+        else qn = geom_of_strided(s, snc);
         if (more && qn.fast) {
             const uint4 *src = reinterpret_cast<const uint4 *>(qn.base + qn.n0 - 1 - qn.mis);
             raw = src[lane];
@@ -478,7 +592,7 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
             }
             if (ml.z >> 8) melv[wave][slot * MEL + (ml.z & 0xff)] = (int)((unsigned)(acc >> t.mel_shift) & 0xFFFFu);
         }
-        if (lane == 0) rowsh[wave][slot] = (long long)c.ch * g.frames_per_ch + c.f;
+        if (lane == 0) rowsh[wave][slot] = RUNS ? c.out_row + c.f : (long long)sc.ch * g.frames_per_ch + sc.f;
         ++slot;
         wave_fence();
 
@@ -525,16 +639,21 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
             wave_fence();
         }
 
-        c = nc;
+        if constexpr (RUNS) {
+            c = nc;
+            kc = kn;
+        } else {
+            sc = snc;
+        }
         q = qn;
     }
 }
 
 inline const char *kernel_name() { return "mfcc_fixed512_kernel"; }
 
-inline void launch(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, int n_cu, hipStream_t stream) {
-    const long long total = s.total_frames;
-    long long blocks = (total + kWaves - 1) / kWaves;
+inline void launch_impl(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, int n_cu, hipStream_t stream,
+                        const RaggedRec *recs, int n_recs, long long total) {
+    long long blocks = (total + 4 * kWaves - 1) / (4 * kWaves);
     // Many more workgroups than are resident (6 per CU by registers and LDS).  Measured on config 3, kernel ms: the
     // exactly resident grid 3.57, 2 x 3.32, 4 x 3.19, 8 x 3.11, 16 x 3.08, 32 x 3.10, 64 x 3.17 -- and with round 2's
     // register-resident tables (4 waves per SIMD) 3.78 at 1 x, 3.20 at 16 x.  A grid that is merely full leaves slots
@@ -546,14 +665,50 @@ inline void launch(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, i
     if (blocks < 1) blocks = 1;
     Geom g;
     g.frames_per_ch = s.frames_per_ch;
-    g.n_ch = (int)(total / s.frames_per_ch);
-    const long long stride = blocks * kWaves;
-    g.step_ch = (int)(stride / s.frames_per_ch);
-    g.step_f = stride % s.frames_per_ch;
-    if (t.n_mel == 16)
-        hipLaunchKernelGGL(mfcc_fixed512_kernel<16>, dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
-    else
-        hipLaunchKernelGGL(mfcc_fixed512_kernel<32>, dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    g.n_ch = recs ? n_recs : (int)(total / s.frames_per_ch);
+    g.recs = recs;
+    if (recs) {
+        // consecutive frames per wave, a multiple of the frames per log2 + DCT pass
+        long long chunk = (total + blocks * kWaves - 1) / (blocks * kWaves);
+        chunk = (chunk + 3) & ~3ll;
+        g.chunk = (int)chunk;
+        g.step_f = 0;
+        g.step_ch = 0;
+        blocks = (total + chunk * kWaves - 1) / (chunk * kWaves);
+        if (t.n_mel == 16)
+            hipLaunchKernelGGL((mfcc_fixed512_kernel<16, true>), dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+        else
+            hipLaunchKernelGGL((mfcc_fixed512_kernel<32, true>), dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    } else {
+        blocks = (total + kWaves - 1) / kWaves < cap ? (total + kWaves - 1) / kWaves : cap;
+        const long long stride = blocks * kWaves;
+        g.chunk = 0;
+        g.step_ch = (int)(stride / s.frames_per_ch);
+        g.step_f = stride % s.frames_per_ch;
+        if (t.n_mel == 16)
+            hipLaunchKernelGGL((mfcc_fixed512_kernel<16, false>), dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+        else
+            hipLaunchKernelGGL((mfcc_fixed512_kernel<32, false>), dim3((unsigned)blocks), dim3(64 * kWaves), 0, stream, s, t, g, out);
+    }
+}
+
+// the plain call: channels of one length
+inline void launch(const mfcc_k::StreamDesc &s, const Tables &t, int16_t *out, int n_cu, hipStream_t stream) {
+    launch_impl(s, t, out, n_cu, stream, nullptr, 0, s.total_frames);
+}
+
+// a ragged corpus straight out of the caller's buffer: d_recs (device) = one record per utterance WITH frames, in order
+inline void launch_ragged(const int16_t *d_pcm, const RaggedRec *d_recs, int n_recs, long long total_frames, int hop,
+                          const Tables &t, int16_t *out, int n_cu, hipStream_t stream) {
+    mfcc_k::StreamDesc s;
+    s.pcm = d_pcm;
+    s.ch_stride = 0;
+    s.n_samples = 0;
+    s.halo = 0;
+    s.frames_per_ch = 1;
+    s.total_frames = total_frames;
+    s.hop = hop;
+    launch_impl(s, t, out, n_cu, stream, d_recs, n_recs, total_frames);
 }
 
 }  // namespace mfcc_fixed512

@@ -150,6 +150,22 @@ struct RaggedTables {
     const RaggedTile *tiles; // [n_tiles]
     int n_tiles;
 };
+// A record is read through the CONSTANT address space (written by ragged_tile_map_kernel before the launch, never by
+// this kernel): only then does the compiler fetch it with a scalar load.  As plain global memory it became vector loads
+// plus v_readfirstlane -- and a vmcnt wait, which in the parker waves means waiting for the window fetch in flight.
+typedef const long long __attribute__((address_space(4))) ConstLL;
+__device__ __forceinline__ RaggedTile load_tile_record(const RaggedTile *tiles, unsigned v) {
+    const ConstLL *r = reinterpret_cast<const ConstLL *>(reinterpret_cast<uintptr_t>(tiles + v));
+    const long long a = r[0], b = r[1], c = r[2], d = r[3];
+    RaggedTile t;
+    t.pcm_off = a;
+    t.out_row = b;
+    t.n_samples = (int)(c & 0xffffffffll);
+    t.frames = (int)(c >> 32);
+    t.t_hi = (int)(d & 0xffffffffll);
+    t.t_in = (int)(d >> 32);
+    return t;
+}
 
 // One role's walk over one group's tiles (virtual workgroup v0, stride gv): where the tile's samples are, how its
 // window lies in its stream, where its rows go.  RAGGED = false is the arithmetic cursor of the plain call.
@@ -178,7 +194,7 @@ struct TileStream {
     __device__ __forceinline__ void prefetch(const RaggedTables &r) {
         if constexpr (RAGGED) {
             const unsigned vn = v + (unsigned)gv;
-            if ((int)vn < r.n_tiles) nx = r.tiles[vn];
+            if ((int)vn < r.n_tiles) nx = load_tile_record(r.tiles, vn);
         }
     }
     __device__ __forceinline__ void start(const mfcc_k::StreamDesc &s, const LaunchGeom &g, const RaggedTables &r,
@@ -195,7 +211,7 @@ struct TileStream {
             c.t_in = 0;
             c.ptr = s.pcm;
             nx = RaggedTile{0, 0, 0, 0, -1, 0};
-            if ((int)v < r.n_tiles) adopt(s, r.tiles[v], n_cep, out);
+            if ((int)v < r.n_tiles) adopt(s, load_tile_record(r.tiles, v), n_cep, out);
             prefetch(r);
         } else {
             c = cursor_of(s, g, v0);

@@ -637,6 +637,41 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
             return MFCC_HIP_ERROR_OTHER;
         }
     }
+    // Fixed contract on the fused kernel: the same -- one record per utterance with frames, the kernel's waves walk
+    // consecutive frames and step from one utterance into the next (kernel_fixed512.hpp)
+    bool rec_fits = n_utt < (size_t(1) << 31);       // the records' int fields (else: pack and gather, below)
+    for (size_t u = 0; u < n_utt && rec_fits; ++u) rec_fits = offsets[u + 1] - offsets[u] < (size_t(1) << 31);
+    if (fixed && h->fixed512_ok && std::is_same<OutT, int16_t>::value && rec_fits) {
+        static_assert(sizeof(mfcc_fixed512::RaggedRec) == 4 * sizeof(long long), "record layout");
+        mfcc_fixed512::RaggedRec *rr = reinterpret_cast<mfcc_fixed512::RaggedRec *>(desc);
+        size_t n_recs = 0;
+        for (size_t u = 0; u < n_utt; ++u) {
+            const size_t n = offsets[u + 1] - offsets[u];
+            const size_t nf = frame_offsets[u + 1] - frame_offsets[u];
+            if (!nf) continue;
+            mfcc_fixed512::RaggedRec c;
+            c.pcm_off = (long long)offsets[u];
+            c.out_row = (long long)frame_offsets[u];
+            c.n_samples = (int)n;
+            c.frames = (int)nf;
+            c.pad0 = c.pad1 = 0;
+            rr[n_recs++] = c;                        // u >= n_recs: never overwrites a record not yet read
+        }
+        {
+            const size_t rec_bytes = n_recs * sizeof(mfcc_fixed512::RaggedRec);
+            rc = ensure(h, &h->d_in, &h->d_in_bytes, rec_bytes + 64);
+            if (rc) return rc;
+            if ((rc = scratch_acquire(h))) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->d_in, rr, rec_bytes, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipEventRecord(pd->copied, h->stream));
+            pd->in_flight = true;
+            mfcc_fixed512::launch_ragged(d_pcm, static_cast<const mfcc_fixed512::RaggedRec *>(h->d_in), (int)n_recs,
+                                         (long long)total, h->r.hop, h->x5, reinterpret_cast<int16_t *>(d_out), h->n_cu,
+                                         h->stream);
+            HIP_TRY(h, hipGetLastError());
+            return scratch_release(h);
+        }
+    }
     const size_t F = pos / hop, len = pos + nfft + hop;
     desc[4 * last_with_frames + 3] = (long long)len;     // the last one also zeroes the tail of the stream
     const size_t desc_bytes = 7 * n_utt * sizeof(long long);

@@ -9,12 +9,13 @@ with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, samplerate=int(os.enviro
         # ragged: utterances packed back to back (no gaps) in a fresh buffer
         offs = np.zeros(n_utt + 1, dtype=np.uint64); offs[1:] = np.cumsum(lens, dtype=np.uint64)
         buf = torch.cat([flat[u * n:u * n + lens[u]] for u in range(n_utt)]) if name == "ragged" else flat
-        out, fo = m.process_packed(buf, offs)
+        fx = bool(int(os.environ.get('RAG_FIXED', '0')))
+        out, fo = m.process_packed(buf, offs, fixed=fx)
         torch.cuda.synchronize()
-        for _ in range(3): m.process_packed(buf, offs, out=out)
+        for _ in range(3): m.process_packed(buf, offs, fixed=fx, out=out)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(10): m.process_packed(buf, offs, out=out)
+        for _ in range(10): m.process_packed(buf, offs, fixed=fx, out=out)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(name, "frames", int(fo[-1]), "ms per corpus %.3f" % (dt * 1e3), "G frames/s %.3f" % (int(fo[-1]) / dt / 1e9))
