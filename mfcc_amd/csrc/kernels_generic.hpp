@@ -79,6 +79,27 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
     __shared__ float  melv[kWavesPerBlock][kMaxMel];
     __shared__ float  melw[NFFT + 8];           // the filterbank weights, once per workgroup: a filter's tap loop would
     for (int i = threadIdx.x; i < t.mel_w_total; i += kBlock) melw[i] = t.mel_w[i];   // otherwise wait for a global load per tap
+    // ... and so would every butterfly for its twiddles: up to 512 points the window, both twiddle tables and (when small
+    // enough) the DCT rows are staged too -- what round 2 found on the fixed-point twin of this kernel (SQ_WAIT_ANY 59 %
+    // on flat loads): 512 points 10.2 -> 7.2 ms.  At 1024 points the tables would take the LDS that keeps a second and
+    // third workgroup on the CU (2.28 -> 3.38 ms, measured): there they stay in global memory.
+    constexpr bool kStage = NFFT <= 512;
+    constexpr int kDctLds = kStage ? 1024 : 1;
+    __shared__ float  winl[kStage ? NFFT : 1];
+    __shared__ float2 twl[kStage ? M : 1];
+    __shared__ float2 twsl[kStage ? M + 1 : 1];
+    __shared__ float  dctl[kDctLds];
+    const bool dct_in_lds = kStage && t.n_cep * t.n_mel <= kDctLds;
+    if constexpr (kStage) {
+        for (int i = threadIdx.x; i < NFFT; i += kBlock) winl[i] = t.window[i];
+        for (int i = threadIdx.x; i < M; i += kBlock) twl[i] = t.tw_fft[i];
+        for (int i = threadIdx.x; i <= M; i += kBlock) twsl[i] = t.tw_split[i];
+        if (dct_in_lds)
+            for (int i = threadIdx.x; i < t.n_cep * t.n_mel; i += kBlock) dctl[i] = t.dct[i];
+    }
+    const float *const win_p = kStage ? winl : t.window;
+    const float2 *const tw_p = kStage ? twl : t.tw_fft;
+    const float2 *const tws_p = kStage ? twsl : t.tw_split;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             float x1 = valid ? sample_at(s, base, n0 + i - 1) : 0.0f;
             // y[0] = x[0] for the very first sample of a stream: history is 0 there
             float y = x0 - 0.96875f * x1;
-            za[i] = y * t.window[i];
+            za[i] = y * win_p[i];
         }
         double dc = 0.0;
         if (t.window_d) {                       // uniform: X[0] = sum w y in double (y is exact)
@@ -127,9 +148,9 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             for (int j = lane; j < M / 4; j += 64) {
                 const int k = j & (Ns - 1);
                 float2 v0 = src[j];
-                float2 v1 = cmul(src[j + M / 4], t.tw_fft[k * tstride]);
-                float2 v2 = cmul(src[j + 2 * (M / 4)], t.tw_fft[2 * k * tstride]);
-                float2 v3 = cmul(src[j + 3 * (M / 4)], t.tw_fft[3 * k * tstride]);
+                float2 v1 = cmul(src[j + M / 4], tw_p[k * tstride]);
+                float2 v2 = cmul(src[j + 2 * (M / 4)], tw_p[2 * k * tstride]);
+                float2 v3 = cmul(src[j + 3 * (M / 4)], tw_p[3 * k * tstride]);
                 float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
                 float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
                 float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             for (int j = lane; j < M / 2; j += 64) {
                 const int k = j & (Ns - 1);
                 float2 v0 = src[j];
-                float2 v1 = cmul(src[j + M / 2], t.tw_fft[k * tstride]);
+                float2 v1 = cmul(src[j + M / 2], tw_p[k * tstride]);
                 const int j0 = ((j - k) << 1) + k;
                 dst[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
                 dst[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
             float er = 0.5f * (a.x + b.x), ei = 0.5f * (a.y - b.y);      // E = (a + conj b)/2
             float dr = a.x - b.x, di = a.y + b.y;                         // a - conj b
             float orr = 0.5f * di, oi = -0.5f * dr;                       // O = -i/2 (a - conj b)
-            float2 w = t.tw_split[k];
+            float2 w = tws_p[k];
             float xr = er + (w.x * orr - w.y * oi);
             float xi = ei + (w.x * oi + w.y * orr);
             P[k] = (k == 0 && t.window_d) ? (float)(dc * dc) : xr * xr + xi * xi;
@@ -185,9 +206,14 @@ __global__ __launch_bounds__(kBlock) void mfcc_float_generic_kernel(StreamDesc s
 
         // DCT-II, first n_cep rows (cells 38-39)
         if (valid && lane < t.n_cep) {
-            const float *d = t.dct + lane * t.n_mel;
             float acc = 0.0f;
-            for (int n = 0; n < t.n_mel; ++n) acc = fmaf(d[n], melv[wave][n], acc);
+            if (dct_in_lds) {
+                const float *d = dctl + lane * t.n_mel;
+                for (int n = 0; n < t.n_mel; ++n) acc = fmaf(d[n], melv[wave][n], acc);
+            } else {
+                const float *d = t.dct + lane * t.n_mel;
+                for (int n = 0; n < t.n_mel; ++n) acc = fmaf(d[n], melv[wave][n], acc);
+            }
             out[fid * t.n_cep + lane] = acc;
         }
         wave_sync();
