@@ -425,19 +425,19 @@ def test_fixed_fused_kernel_other_sample_rates(mfcc_amd):
     filterbank asserts."""
     pcm = np.concatenate([mf.synth_pcm(30000, seed=21), np.full(700, -32768, np.int16), np.full(700, 32767, np.int16)])
     ran = 0
-    for sr in (8000, 11025, 22050, 32000, 44100, 48000):
-        with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=32, samplerate=sr, pad_mode="stream") as m:
+    for sr, nfil in [(r, 32) for r in (8000, 11025, 22050, 32000, 44100, 48000)] + [(r, 16) for r in (8000, 22050, 48000)]:
+        with mfcc_amd.MFCC(nfft=512, nfilters=nfil, nceptrums=nfil, samplerate=sr, pad_mode="stream") as m:
             try:
-                ref = mx.mfcc_fixed_ref(pcm, nceptrums=32, sample_rate=float(sr))
+                ref = mx.mfcc_fixed_ref(pcm, nfilters=nfil, nceptrums=nfil, sample_rate=float(sr))
             except AssertionError:
                 with pytest.raises(mfcc_amd.MfccHipError) as e:
                     m.process_fixed(pcm)
                 assert e.value.code == -105, sr
                 continue
-            assert m.kernel_name(fixed=True) == "mfcc_fixed512_kernel", sr
-            assert np.array_equal(m.process_fixed(pcm), ref), sr
+            assert m.kernel_name(fixed=True) == "mfcc_fixed512_kernel", (sr, nfil)
+            assert np.array_equal(m.process_fixed(pcm), ref), (sr, nfil)
             ran += 1
-    assert ran >= 4
+    assert ran >= 6
 
 
 @pytest.mark.parametrize("pad", ["stream", "notebook"])
