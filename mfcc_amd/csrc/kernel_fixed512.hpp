@@ -386,7 +386,10 @@ void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__res
     __syncthreads();
     const int br6 = (int)(__brev((unsigned)lane) >> 26);
     
-    const long long wid = (long long)blockIdx.x * kWaves + wave;
+    // XCD-aware order (kernel_fused512_w12.hpp): neighbouring workgroups, whose frames overlap, share an XCD's L2
+    const unsigned nwg = gridDim.x;
+    const unsigned bid = (nwg & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3);
+    const long long wid = (long long)bid * kWaves + wave;
     // RUNS: this wave's run of consecutive frames; plain: its first frame, then strides of all waves of the grid
     FrameCursor c = {};
     StreamConst kc = {0, 0, 0};

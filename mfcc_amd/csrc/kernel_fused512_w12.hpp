@@ -276,7 +276,12 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
     auto Sf = [&](int gi) { return lds + gi * kGroupWords + kTile * kTFrame + kTile * kVStride + kQGroupWords; };
 
     // tiles of the two groups: virtual workgroups 2 w and 2 w + 1 of a grid of 2 x gridDim.x
-    const unsigned va = 2u * blockIdx.x, vb = va + 1u;
+    // XCD-aware tile order: workgroup b runs on XCD b mod 8 (round-robin dispatch), and consecutive tiles share 342
+    // samples of their windows -- so consecutive tile pairs go to workgroups of the SAME XCD (one L2 sees both windows):
+    // the workgroups of an XCD take a contiguous eighth of the logical workgroup ids
+    const unsigned nwg = gridDim.x;
+    const unsigned bid = (nwg & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3);
+    const unsigned va = 2u * bid, vb = va + 1u;
     const int n_tiles = RAGGED ? rag.n_tiles : g.tiles_per_ch * g.n_ch;   // < 2^30 (host check)
     const int gv = 2 * (int)gridDim.x;
     const int nA = (int)va < n_tiles ? (n_tiles - (int)va + gv - 1) / gv : 0;
