@@ -275,8 +275,9 @@ struct Geom {
     const RaggedRec *recs;            // nullptr: the plain multi-channel call
 };
 
-// the plain call's cursor, exactly as round 2 measured it (a shared cursor type for both walks compiled 2.6 % slower
-// on config 3 -- the same instruction counts, a different schedule -- so the two walks keep their own few lines)
+// the plain call's cursor.  The two walks keep their own few lines of cursor code: versions with ONE cursor type for
+// both (copied as a whole per frame, or captured by a [&] lambda) had the compiler keep the cursors in scratch memory --
+// 3.17 and 5.78 ms against 3.10 on config 3, with "VGPRs Spill: 0" in the remarks; ScratchSize is the line to read
 struct StridedCursor {
     int ch;
     long long f;
@@ -290,7 +291,7 @@ __device__ __forceinline__ const ConstLL *rec_ptr(const RaggedRec *recs, int u) 
 }
 
 // A wave's position: the stream (channel / utterance) it is in and the frame there.  Kept small: the kernel holds two of
-// them (this frame, the next one) in scalar registers, and a cursor that carried the stream's constants along spilled.
+// them (this frame, the next one) in scalar registers; the stream's constants travel separately (StreamConst).
 struct FrameCursor {
     int u, f;                // f < 2^31: a channel that fills the device's memory has < 2^30 frames
     const int16_t *base;     // the stream's first sample
@@ -352,7 +353,8 @@ __device__ __forceinline__ FrameGeom geom_of(const int16_t *base, const FrameCur
 // RUNS = false, the plain call: wave w takes the frames w, w + W, w + 2 W ... (W = all waves of the grid) -- at any
 // moment the resident waves work on neighbouring frames.  RUNS = true, a ragged corpus: wave w takes `chunk` CONSECUTIVE
 // frames, so that moving on is ++f with a rare step into the next utterance (a strided walk would have to search the
-// utterance of every frame).  Measured on config 3: runs 3.17 ms, strides 3.09 -- hence both.
+// utterance of every frame).  Same speed: 10 000 equal utterances as channels (strides) 7.99 ms, as a ragged corpus of
+// five lengths (runs) 7.94 ms.
 template <int MEL, bool RUNS>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void mfcc_fixed512_kernel(mfcc_k::StreamDesc s, Tables t, Geom g, int16_t *__restrict__ out) {

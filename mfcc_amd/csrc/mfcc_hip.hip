@@ -598,8 +598,9 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
         if (uniform)
             return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
     }
-    // Float contract on the twelve-wave kernel: no packed copy at all -- per-utterance records and a tile map, the
-    // kernel reads every utterance where it lies and writes its rows where they belong (kernel_fused512_w12.hpp)
+    // Float contract on the twelve-wave kernel: no packed copy at all -- per-utterance records, expanded on the device
+    // into one record per tile; the kernel reads every utterance where it lies and writes its rows where they belong
+    // (kernel_fused512_w12.hpp)
     if (!fixed && use_fused(h) && h->fused_w12 && std::is_same<OutT, float>::value) {
         static_assert(sizeof(mfcc_fused12::RaggedChan) == 4 * sizeof(long long), "record layout");
         mfcc_fused12::RaggedChan *rc_host = reinterpret_cast<mfcc_fused12::RaggedChan *>(desc);   // 4 long longs each
