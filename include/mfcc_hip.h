@@ -95,6 +95,10 @@ int  mfcc_hip_default_params(mfcc_hip_params *p);
 /* validates, builds the constant tables on the host, uploads them, creates a stream.
  * Fails with MFCC_HIP_ERROR_NOT_FOUND when no GPU is present: there is no CPU fallback. */
 int  mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out);
+/* Lifetime rule: a handle that still has streaming sessions (mfcc_hip_stream_create below) is only MARKED
+ * by mfcc_hip_destroy -- its stream, tables and scratch stay valid for those sessions, no new session can be
+ * opened on it and no other call may be made with it -- and is freed by the mfcc_hip_stream_destroy of its
+ * last session.  Without live sessions it is freed at once.  Either order of the destroy calls is safe. */
 void mfcc_hip_destroy(mfcc_hip_handle *h);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream).  NULL means the HIP
  * null (default) stream -- which is what torch uses unless told otherwise -- NOT "none". */
@@ -227,6 +231,8 @@ typedef struct mfcc_hip_stream mfcc_hip_stream;
 
 /* fixed = 0: float contract (out = float), fixed = 1: RTL contract (out = int16_t) */
 int  mfcc_hip_stream_create(mfcc_hip_handle *h, int fixed, mfcc_hip_stream **out);
+/* frees the session's device buffers; if its handle was already given to mfcc_hip_destroy and this was the
+ * handle's last session, the handle is freed here (see the lifetime rule at mfcc_hip_destroy) */
 void mfcc_hip_stream_destroy(mfcc_hip_stream *s);
 /* `mfcc_softreset` (software/main.c:21-34): drop the pending samples, history back to 0 */
 int  mfcc_hip_stream_reset(mfcc_hip_stream *s);

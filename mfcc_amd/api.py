@@ -303,12 +303,16 @@ class MFCC:
             raise ValueError("offsets run past the end of flat")
         self._check_device(flat)
         lens = np.diff(offsets.astype(np.int64))
-        if (lens < 0).any():
+        if n and int(lens.min()) < 0:
             raise ValueError("offsets must not decrease")
         fo = np.zeros(n + 1, dtype=np.uint64)
-        uniq = np.unique(lens)
-        nf_of = {int(v): self.num_frames(int(v)) for v in uniq}
-        nf = int(sum(nf_of[int(v)] for v in lens)) if len(uniq) > 1 else (nf_of[int(uniq[0])] * n if n else 0)
+        # this runs once per step of a sharded corpus (bench.py enqueue_us_per_step): equal lengths -- config 5 as
+        # BASELINE defines it -- need one frame count, not a table of them
+        if n and int(lens.min()) == int(lens.max()):
+            nf = self.num_frames(int(lens[0])) * n
+        else:
+            uniq, counts = np.unique(lens, return_counts=True)
+            nf = int(sum(self.num_frames(int(v)) * int(c) for v, c in zip(uniq, counts)))
         odt = torch.int16 if fixed else torch.float32
         if out is None:
             out = torch.empty((nf, self.nceptrums), device=flat.device, dtype=odt)
@@ -375,7 +379,8 @@ class MfccStream:
         self._s = s
 
     def close(self):
-        if getattr(self, "_s", None) and getattr(self._m, "_h", None):
+        # either order is safe: a handle closed first is kept alive by the library until its last session goes
+        if getattr(self, "_s", None):
             self._lib.mfcc_hip_stream_destroy(self._s)
         self._s = None
 

@@ -147,6 +147,10 @@ struct mfcc_hip_handle {
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
+    // streaming sessions opened on this handle that are still alive.  mfcc_hip_destroy with live sessions only marks
+    // the handle; the last mfcc_hip_stream_destroy then tears it down (include/mfcc_hip.h: lifetime)
+    int n_sessions = 0;
+    bool destroy_pending = false;
 };
 
 namespace {
@@ -558,18 +562,40 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
     const size_t hop = size_t(h->r.hop), nfft = size_t(h->r.nfft), ncep = size_t(h->r.n_cep);
     DeviceGuard guard(h->device);
-    mfcc_hip_handle::PinnedDesc *pd = nullptr;     // [0, 4n): pack descriptors, [4n, 7n): row-gather descriptors, in
-    int rc = desc_acquire(h, 7 * n_utt, &pd);      // pinned memory: the H2D copy below is asynchronous
+    // A corpus of equal-length utterances lying back to back (BASELINE config 5: 10 000 x 10 s) IS a multi-channel
+    // stream, channel stride = utterance length: no packing copy, no row gather, no descriptors, the same bits (every
+    // channel of the plain call starts from reset, its frames are the utterance's frames and the rows come out dense).
+    // Checked first: this is the per-step host work of a sharded corpus (bench.py `enqueue_us_per_step`).
+    if (n_utt >= 1 && offsets[1] >= offsets[0]) {
+        const size_t n0 = offsets[1] - offsets[0];
+        const size_t nf0 = count_frames(h->r, n0);
+        bool uniform = nf0 > 0;
+        for (size_t u = 1; u < n_utt && uniform; ++u) uniform = offsets[u + 1] - offsets[u] == n0;
+        if (uniform) {
+            if (!d_pcm) return MFCC_HIP_ERROR_INVALID_PARAM;
+            for (size_t u = 0; u <= n_utt; ++u) frame_offsets[u] = u * nf0;
+            if (!d_out || cap < n_utt * nf0 * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
+            return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
+        }
+    }
+    // [0, 4n): pack descriptors, [4n, 7n): row-gather descriptors, [7n, 11n): the fused kernels' per-utterance records
+    // (their own region: a corpus the records cannot describe falls through to pack-and-gather with [0, 7n) intact);
+    // in pinned memory: the H2D copies below are asynchronous
+    mfcc_hip_handle::PinnedDesc *pd = nullptr;
+    int rc = desc_acquire(h, 11 * n_utt, &pd);
     if (rc) return rc;
     long long *desc = pd->p;
+    long long *rec_area = desc + 7 * n_utt;
     for (size_t i = 0; i < 7 * n_utt; ++i) desc[i] = 0;
     size_t last_with_frames = n_utt;
     size_t pos = 0, total = 0;
+    bool rec_fits = n_utt < (size_t(1) << 31);       // the records' int fields (else: pack and gather, below)
     frame_offsets[0] = 0;
     for (size_t u = 0; u < n_utt; ++u) {
         if (offsets[u + 1] < offsets[u]) return MFCC_HIP_ERROR_INVALID_PARAM;
         const size_t n = offsets[u + 1] - offsets[u];
         if (n && !d_pcm) return MFCC_HIP_ERROR_INVALID_PARAM;
+        if (n >= (size_t(1) << 31)) rec_fits = false;
         const size_t nf = count_frames(h->r, n);
         desc[4 * u] = (long long)offsets[u];
         desc[4 * u + 1] = (long long)pos;
@@ -588,22 +614,12 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
     }
     if (total == 0) return MFCC_HIP_SUCCESS;
     if (!d_out || cap < total * ncep) return MFCC_HIP_ERROR_BUFFER_SMALL;
-    // A corpus of equal-length utterances lying back to back (BASELINE config 5: 10 000 x 10 s) IS a multi-channel
-    // stream, channel stride = utterance length: no packing copy, no row gather, the same bits (every channel of
-    // the plain call starts from reset, its frames are the utterance's frames and the rows come out dense).
-    {
-        const size_t n0 = offsets[1] - offsets[0];
-        bool uniform = n_utt >= 1 && count_frames(h->r, n0) > 0;
-        for (size_t u = 1; u < n_utt && uniform; ++u) uniform = offsets[u + 1] - offsets[u] == n0;
-        if (uniform)
-            return launch(h, fixed, d_pcm + offsets[0], n0, n0, n_utt, 0, d_out, nullptr);
-    }
     // Float contract on the twelve-wave kernel: no packed copy at all -- per-utterance records, expanded on the device
     // into one record per tile; the kernel reads every utterance where it lies and writes its rows where they belong
     // (kernel_fused512_w12.hpp)
-    if (!fixed && use_fused(h) && h->fused_w12 && std::is_same<OutT, float>::value) {
+    if (!fixed && use_fused(h) && h->fused_w12 && std::is_same<OutT, float>::value && rec_fits) {
         static_assert(sizeof(mfcc_fused12::RaggedChan) == 4 * sizeof(long long), "record layout");
-        mfcc_fused12::RaggedChan *rc_host = reinterpret_cast<mfcc_fused12::RaggedChan *>(desc);   // 4 long longs each
+        mfcc_fused12::RaggedChan *rc_host = reinterpret_cast<mfcc_fused12::RaggedChan *>(rec_area);   // 4 long longs each
         long long n_tiles = 0;
         for (size_t u = 0; u < n_utt; ++u) {
             const size_t n = offsets[u + 1] - offsets[u];
@@ -618,7 +634,6 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
             c.tile0 = (int)n_tiles;
             rc_host[u] = c;
             n_tiles += tiles;
-            if (n >= (size_t(1) << 31)) n_tiles = (1ll << 40);          // an utterance beyond the record's int fields
         }
         if (n_tiles < (1ll << 30)) {
             const size_t chan_bytes = n_utt * sizeof(mfcc_fused12::RaggedChan);
@@ -636,17 +651,15 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
                 HIP_TRY(h, hipGetLastError());
                 return scratch_release(h);
             }
-            // not launched (cannot happen once fused_w12 is set): rebuild the pack descriptors below
-            return MFCC_HIP_ERROR_OTHER;
+            return MFCC_HIP_ERROR_OTHER;               // not launched: cannot happen once fused_w12 is set
         }
+        // more tiles than the tile map's int index: pack and gather below (the pack descriptors are untouched)
     }
     // Fixed contract on the fused kernel: the same -- one record per utterance with frames, the kernel's waves walk
     // consecutive frames and step from one utterance into the next (kernel_fixed512.hpp)
-    bool rec_fits = n_utt < (size_t(1) << 31);       // the records' int fields (else: pack and gather, below)
-    for (size_t u = 0; u < n_utt && rec_fits; ++u) rec_fits = offsets[u + 1] - offsets[u] < (size_t(1) << 31);
     if (fixed && h->fixed512_ok && std::is_same<OutT, int16_t>::value && rec_fits) {
         static_assert(sizeof(mfcc_fixed512::RaggedRec) == 4 * sizeof(long long), "record layout");
-        mfcc_fixed512::RaggedRec *rr = reinterpret_cast<mfcc_fixed512::RaggedRec *>(desc);
+        mfcc_fixed512::RaggedRec *rr = reinterpret_cast<mfcc_fixed512::RaggedRec *>(rec_area);
         size_t n_recs = 0;
         for (size_t u = 0; u < n_utt; ++u) {
             const size_t n = offsets[u + 1] - offsets[u];
@@ -658,7 +671,7 @@ int process_ragged_dev(mfcc_hip_handle *h, bool fixed, const int16_t *d_pcm, con
             c.n_samples = (int)n;
             c.frames = (int)nf;
             c.pad0 = c.pad1 = 0;
-            rr[n_recs++] = c;                        // u >= n_recs: never overwrites a record not yet read
+            rr[n_recs++] = c;
         }
         {
             const size_t rec_bytes = n_recs * sizeof(mfcc_fixed512::RaggedRec);
@@ -940,6 +953,10 @@ int mfcc_hip_create(const mfcc_hip_params *p, mfcc_hip_handle **out) {
 
 void mfcc_hip_destroy(mfcc_hip_handle *h) {
     if (!h) return;
+    if (h->n_sessions > 0) {           // sessions still use the handle's stream and tables: the last one frees it
+        h->destroy_pending = true;
+        return;
+    }
     DeviceGuard guard(h->device);
     if (h->scratch_used) (void)hipEventSynchronize(h->scratch_done);     // scratch may be in use on a caller's stream
     if (h->own_stream) {
@@ -1207,11 +1224,13 @@ extern "C" {
 int mfcc_hip_stream_create(mfcc_hip_handle *h, int fixed, mfcc_hip_stream **out) {
     if (!h || !out) return MFCC_HIP_ERROR_INVALID_PARAM;
     *out = nullptr;
+    if (h->destroy_pending) return MFCC_HIP_ERROR_INVALID_PARAM;        // the handle was already given back
     if (fixed && !h->fixed_ok) return MFCC_HIP_ERROR_UNSUPPORTED;
     mfcc_hip_stream *s = new (std::nothrow) mfcc_hip_stream();
     if (!s) return MFCC_HIP_ERROR_NO_MEM;
     s->h = h;
     s->fixed = fixed != 0;
+    ++h->n_sessions;
     DeviceGuard guard(h->device);
     int rc = stream_reserve(s, size_t(h->r.nfft) * 8, size_t(64) * size_t(h->r.n_cep) * sizeof(float));
     if (rc) {
@@ -1224,12 +1243,16 @@ int mfcc_hip_stream_create(mfcc_hip_handle *h, int fixed, mfcc_hip_stream **out)
 
 void mfcc_hip_stream_destroy(mfcc_hip_stream *s) {
     if (!s) return;
-    DeviceGuard guard(s->h->device);
-    (void)hipStreamSynchronize(s->h->stream);
-    for (int i = 0; i < 2; ++i)
-        if (s->buf[i]) (void)hipFree(s->buf[i]);
-    if (s->d_out) (void)hipFree(s->d_out);
-    delete s;
+    mfcc_hip_handle *h = s->h;
+    {
+        DeviceGuard guard(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        for (int i = 0; i < 2; ++i)
+            if (s->buf[i]) (void)hipFree(s->buf[i]);
+        if (s->d_out) (void)hipFree(s->d_out);
+        delete s;
+    }
+    if (--h->n_sessions == 0 && h->destroy_pending) mfcc_hip_destroy(h);
 }
 
 int mfcc_hip_stream_reset(mfcc_hip_stream *s) {

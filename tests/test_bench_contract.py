@@ -2,6 +2,7 @@
 `python bench.py` run on the GPU box (profiles/r01_bench.json) and on bench.py's static text."""
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -50,5 +51,9 @@ def test_bench_only_uses_the_oracle_for_the_cpu_baseline():
     j = src.rindex("\ndef ", 0, i)
     assert src[j:].startswith("\ndef cpu_baseline("), "the oracle import must sit inside the cpu_baseline leg"
     # and that leg only runs when asked for, on rank 0, outside the timed regions
-    assert src.count("cpu_baseline(") == 3                       # the definition and its two guarded call sites
-    assert "if not args.no_cpu_baseline:" in src and "if with_cpu:" in src
+    # the definition, two guarded call sites on the batch (the sample and config 1's wav) and one on the corpus
+    assert src.count("cpu_baseline(") == 4
+    assert "with_cpu = not args.no_cpu_baseline" in src and src.count("if with_cpu:") == 2
+    for call in re.finditer(r"= cpu_baseline\(", src):
+        head = src.rfind("if with_cpu:", 0, call.start())
+        assert head >= 0 and src.count("\ndef ", head, call.start()) == 0, "unguarded cpu_baseline call"

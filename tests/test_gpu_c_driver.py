@@ -19,6 +19,9 @@ EXE = os.path.join(ROOT, "tests", "bin", "c_driver")
 @pytest.fixture(scope="module")
 def c_driver():
     if not os.path.exists(EXE):                  # normally built by __graft_entry__.build() and shipped with the tree
+        import shutil
+        if shutil.which("gcc") is None:
+            pytest.skip("no gcc on this host and no prebuilt tests/bin/c_driver")
         import __graft_entry__ as g
         g.build_c_driver()
     return EXE
