@@ -18,6 +18,7 @@
 #include "kernels_generic.hpp"
 #include "kernel_fixed512.hpp"
 #include "kernel_fused1024.hpp"
+#include "kernel_fused1024_t8.hpp"
 #include "kernel_fused512.hpp"
 #include "kernel_fused512_w12.hpp"
 #include "tables.hpp"
@@ -117,6 +118,7 @@ struct mfcc_hip_handle {
     bool fused_dense = false;     // the fused kernel's banded MFMA list does not fit this sample rate: all pairs
     bool fused_w12 = false;       // the twelve-wave form of the fused 512 kernel runs (kernel_fused512_w12.hpp)
     bool fused1k_ok = false;      // the fused 1024/341/40 float kernel covers this handle's parameters
+    bool fused1k8_ok = false;     // ... in its eight-frame-tile form (kernel_fused1024_t8.hpp): the one that runs
     bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
     void *arena = nullptr;
@@ -125,6 +127,7 @@ struct mfcc_hip_handle {
     mfcc_fused::FusedTables fu{};
     mfcc_fixed512::Tables x5{};
     mfcc_fused1024::Tables f1k{};
+    mfcc_f1k::Tables f1k8{};
     // descriptor tables of the ragged calls live in pinned host memory, two buffers used in turn: the H2D copy of
     // an asynchronous call reads buffer i while the next call fills buffer 1 - i; the call after that waits for the
     // event recorded behind buffer i's copy before it overwrites it
@@ -322,6 +325,16 @@ int build_tables(mfcc_hip_handle *h) {
                     mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_sched);
     size_t o_f1k = 0;
     if (h->fused1k_ok) o_f1k = a.put(f1k_blob);
+    std::vector<char> f1k8_blob;
+    int f1k8_var = 0;
+    {
+        // diagnostic override for A/B runs: MFCC_HIP_FUSED1024=t16 keeps round 2's sixteen-frame-tile kernel
+        const char *e = std::getenv("MFCC_HIP_FUSED1024");
+        h->fused1k8_ok = !(e && std::strcmp(e, "t16") == 0) && mfcc_f1k::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
+                         mfcc_f1k::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k8_blob, f1k8_var);
+    }
+    size_t o_f1k8 = 0;
+    if (h->fused1k8_ok) o_f1k8 = a.put(f1k8_blob);
 
     HIP_TRY(h, hipMalloc(&h->arena, a.host.size() + 256));
     HIP_TRY(h, hipMemcpy(h->arena, a.host.data(), a.host.size(), hipMemcpyHostToDevice));
@@ -362,6 +375,7 @@ int build_tables(mfcc_hip_handle *h) {
         h->fused_w12 = h->fused_ok && !(e && std::strcmp(e, "w4") == 0);
     }
     if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, f1k_sched, h->f1k);
+    if (h->fused1k8_ok) mfcc_f1k::bind_tables(b + o_f1k8, r.n_cep, f1k8_var, h->f1k8);
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
         h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];
@@ -436,7 +450,10 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
                           mfcc_fused12::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream);
         if (!done && !mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
-    } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
+    } else if (h->fused1k8_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
+               mfcc_f1k::launch(s, h->f1k8, static_cast<float *>(d_out), h->n_cu, h->stream)) {
+        // fused 1024/341/40 kernel launched (eight-frame tiles)
+    } else if (h->fused1k_ok && !h->fused1k8_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
                mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) {
         // fused 1024/341/40 kernel launched
     } else {
@@ -1073,6 +1090,7 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return h->fused_w12 ? mfcc_fused12::kernel_name() : mfcc_fused::kernel_name();
+    if (h->fused1k8_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_f1k::kernel_name();
     if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_fused1024::kernel_name();
     return "mfcc_float_generic_kernel";
 }

@@ -46,6 +46,7 @@ def signal(rng, n, kind):
 ILL = [0, 0]       # bands of noise-like channels set aside / compared (see the docstring)
 EXCL_MAX = [0.0]   # largest |log-mel error| inside the set-aside bands (noise-like channels)
 HARD = []          # DC / square / sine channels, float contract: max coefficient error / max |coefficient|, per channel
+FRAMES_1K = [0, 0]  # fused 1024 kernel (n_cep <= 32 < n_mel): frames with a band set aside / frames compared
 REACH = 1e-7       # a band below this fraction of the frame's mean bin power is beyond fp32's reach
 
 
@@ -57,12 +58,13 @@ def pattern_ok(a, b):
 
 
 def band_compare(g_full, ref_full, st, B, noise_like):
-    """g_full / ref_full: (frames, n_mel) coefficients; st: the oracle's stages.  Returns (ok, why, rel err)."""
+    """g_full / ref_full: (frames, n_mel) coefficients; st: the oracle's stages.  Returns (ok, why, rel err, frames
+    that have a band set aside)."""
     g = g_full.astype(np.float64)
     ok, why = pattern_ok(g, ref_full)
-    if not ok: return False, why, np.inf
+    if not ok: return False, why, np.inf, None
     rows = np.isfinite(ref_full).all(axis=1)
-    if not rows.any(): return True, "", 0.0
+    if not rows.any(): return True, "", 0.0, np.zeros(len(ref_full), bool)
     mel, lm = st["mel"][rows], st["logmel"][rows]
     dl = g[rows] @ B - lm                                        # per-band log-mel error
     w = st["filters"]
@@ -74,7 +76,9 @@ def band_compare(g_full, ref_full, st, B, noise_like):
     dl = np.where(out, 0.0, dl)
     dc = dl @ B.T                                                # back through the DCT: the coefficient error of the kept bands
     rel = float(np.abs(dc).max() / max(np.abs(ref_full[rows]).max(), 1.0))
-    return rel <= 1e-4, "err %.3g of the largest coefficient" % rel, rel
+    aside = np.zeros(len(ref_full), bool)
+    aside[np.flatnonzero(rows)[out.any(axis=1)]] = True
+    return rel <= 1e-4, "err %.3g of the largest coefficient" % rel, rel, aside
 
 
 def one_case(seed):
@@ -133,6 +137,7 @@ def one_case(seed):
         ga = a.process(view, halo=halo).cpu().numpy()
         gaf = af.process(view, halo=halo).cpu().numpy(); gbf = bf.process(view, halo=halo).cpu().numpy()
         names = (af.kernel_name(), bf.kernel_name())
+        name_a = a.kernel_name()
     if ga.shape[1] == 0:
         return fails                               # no frame: nothing to compare
     B = mf.dct_basis(nmel, nmel)
@@ -147,32 +152,54 @@ def one_case(seed):
         if halo:
             ref = ref[1:]
             st = {k: (v[1:] if k in ("power", "mel", "logmel") else v) for k, v in st.items()}
+        if halo and len(ref) == gaf.shape[1] - 1 and n < nfft:
+            continue      # a shard shorter than a frame: the oracle's stream, one hop longer, has no frame of its own here
         noise_like = kinds[c] < 3
-        worst = 0.0
+        worst, aside = 0.0, None
         for name, g in zip(names, (gaf[c], gbf[c])):
             if len(g) != len(ref):
                 fails.append("FLOAT %s %s ch %d: %d frames, oracle %d" % (name, tag, c, len(g), len(ref)))
                 continue
-            ok, why, rel = band_compare(g, ref, st, B, noise_like)
+            ok, why, rel, asd = band_compare(g, ref, st, B, noise_like)
             worst = max(worst, rel)
+            aside = asd if aside is None else aside
             if not ok and (noise_like or os.environ.get("FUZZ_STRICT")):
                 fails.append("FLOAT %s vs float64 oracle %s ch %d: %s" % (name, tag, c, why))
         if not noise_like:
             HARD.append(worst)
-        # the drawn n_cep against the first columns of the all-coefficient run: the same log-mel values, fewer DCT rows
-        a64, f64 = ga[c].astype(np.float64), gaf[c][:, :ncep].astype(np.float64)
-        ok, why = pattern_ok(a64, f64)
-        fin = np.isfinite(f64)
-        if ok and fin.any() and np.abs(a64[fin] - f64[fin]).max() > 1e-6 * max(np.abs(f64[fin]).max(), 1.0):
-            ok, why = False, "err %.3g" % np.abs(a64[fin] - f64[fin]).max()
-        if not ok:
-            fails.append("FLOAT n_cep %d vs n_cep %d of %s %s ch %d: %s" % (ncep, nmel, names[0], tag, c, why))
+        a64 = ga[c].astype(np.float64)
+        if len(a64) != len(ref):
+            continue
+        if name_a == names[0]:
+            # the drawn n_cep against the first columns of the all-coefficient run: the same log-mel values, fewer DCT rows
+            f64 = gaf[c][:, :ncep].astype(np.float64)
+            ok, why = pattern_ok(a64, f64)
+            fin = np.isfinite(f64)
+            if ok and fin.any() and np.abs(a64[fin] - f64[fin]).max() > 1e-6 * max(np.abs(f64[fin]).max(), 1.0):
+                ok, why = False, "err %.3g of %.3g" % (np.abs(a64[fin] - f64[fin]).max(), np.abs(f64[fin]).max())
+            if not ok:
+                fails.append("FLOAT n_cep %d vs n_cep %d of %s %s ch %d: %s" % (ncep, nmel, names[0], tag, c, why))
+        elif aside is not None:
+            # the fused 1024 kernel keeps at most 32 of its 40 coefficients, so its DCT cannot be undone: it is held to
+            # the contract in the coefficient domain on the frames that have no band set aside (counted in FRAMES_1K)
+            r64 = ref[:, :ncep]
+            ok, why = pattern_ok(a64, r64)
+            keep = ~aside & np.isfinite(r64).all(axis=1)
+            if noise_like:
+                FRAMES_1K[0] += int(aside.sum()); FRAMES_1K[1] += len(aside)
+            if ok and keep.any():
+                rel = np.abs(a64[keep] - r64[keep]).max() / max(np.abs(r64[keep]).max(), 1.0)
+                if rel > 1e-4: ok, why = False, "err %.3g of the largest coefficient" % rel
+            if not ok and (noise_like or os.environ.get("FUZZ_STRICT")):
+                fails.append("FLOAT %s vs float64 oracle %s ch %d: %s" % (name_a, tag, c, why))
     return fails
 
 
 def summary():
     s = "bands beyond fp32's reach set aside %d of %d (%.4f %%) on noise-like channels, largest log-mel error inside " \
         "that set %.3g" % (ILL[0], ILL[1], 100.0 * ILL[0] / max(ILL[1], 1), EXCL_MAX[0])
+    if FRAMES_1K[1]:
+        s += "; fused 1024 kernel, coefficient domain: %d of %d frames not compared (a band set aside)" % tuple(FRAMES_1K)
     if HARD:
         h = np.sort(np.array(HARD)[np.isfinite(HARD)])
         if len(h):

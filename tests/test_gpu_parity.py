@@ -217,8 +217,8 @@ def test_fused1024_other_ncep_stream_padding_and_lifter(mfcc_amd, ncep):
     pcm = np.stack([mf.synth_pcm(341 * 40 + 1024 + 55, seed=300 + s) for s in range(3)])
     ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream", nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
     with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=ncep, power_scale=0, pad_mode="stream") as m:
-        # up to 32 coefficients (what the reference tops keep, main.c:13) on the fused kernel; beyond: generic
-        assert m.kernel_name().endswith("fused1024_kernel" if ncep <= 32 else "generic_kernel")
+        # every coefficient count up to n_mel on the fused kernel (the reference tops keep nceptrums = nfilters)
+        assert m.kernel_name().endswith("fused1024_kernel")
         got = m.process(pcm)
         many = m.process_batch([pcm[0], pcm[1][:5000], pcm[2][:1023]])
         assert np.array_equal(many[0], got[0]) and many[2].shape == (1, ncep)
@@ -257,8 +257,8 @@ def test_fused1024_config4_size_periodicity(mfcc_amd, wav_pcm):
 def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
     """The banded MFMA lists of the fused kernels are the band structure of the mel matrix at ONE sample rate; their
     table builders check every non-zero weight is covered.  The 512 kernel switches to its dense instantiation (all 32
-    (k2, block) pairs, any rate).  The 1024 kernel has one schedule per rate (8, 11.025, 16, 22.05, 32 kHz: 17..19
-    operand sets per wave fit its registers); 44.1 / 48 kHz put weight on the DC bin: generic kernel."""
+    (k2, block) pairs, any rate).  The 1024 kernel has three set lists (<= 22.05 kHz, 32 kHz, 44.1 / 48 kHz) and picks the
+    first that covers the rate's matrix."""
     x = mf.synth_pcm(30000, seed=2)
     for nfft, nmel in ((512, 32), (1024, 40)):
         with mfcc_amd.MFCC(nfft=nfft, nfilters=nmel, nceptrums=13, samplerate=sr, power_scale=0) as m:
@@ -266,15 +266,15 @@ def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
             if nfft == 512:
                 assert m.kernel_name().startswith("mfcc_fused512")
             else:
-                assert m.kernel_name() == ("mfcc_fused1024_kernel" if sr <= 32000 else "mfcc_float_generic_kernel"), sr
+                assert m.kernel_name() == "mfcc_fused1024_kernel", sr
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
 
 
-@pytest.mark.parametrize("sr", [8000, 11025, 22050, 32000])
+@pytest.mark.parametrize("sr", [8000, 11025, 22050, 32000, 44100, 48000])
 def test_fused1024_schedules_of_other_rates_vs_generic_and_oracle(mfcc_amd, sr):
-    """Each per-rate schedule of the 1024 kernel: several channels at odd alignments, 32 coefficients, STREAM framing,
+    """Each set list of the 1024 kernel: several channels at odd alignments, 32 coefficients, STREAM framing,
     against the float64 oracle and against the generic kernel on the device."""
     import torch
     nch, n = 3, 341 * 50 + 1024 + 77
