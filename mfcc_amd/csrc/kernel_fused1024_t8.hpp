@@ -39,6 +39,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -46,6 +47,17 @@
 #include "fused_common.hpp"
 #include "kernels_generic.hpp"
 #include "tables.hpp"
+
+// experiment switches (A/B builds, tools/ab1k.sh); the defaults are what ships
+#ifndef F1K_PRESUM
+#define F1K_PRESUM 1        // each wave adds its two column halves (DPP) before the Q write
+#endif
+#ifndef F1K_SPLIT_TAIL
+#define F1K_SPLIT_TAIL 1    // wave 0: sums + log2 before B1, wave 3: DCT behind B1 (0: all of it on wave 3)
+#endif
+#ifndef F1K_TAIL_PRIO
+#define F1K_TAIL_PRIO 0     // s_setprio of the waves with a tail / column-16 job while they do it
+#endif
 
 namespace mfcc_f1k {
 
@@ -64,7 +76,8 @@ constexpr int kSecond = kPieces - kFetchers;      // lanes that take a second pi
 constexpr int kSUsed = 8 * kPieces;               // 3424 fp32 slots
 constexpr int kTwRow = 36;                        // words per n2 row of the twiddle table in LDS (9 16-byte units: the
                                                   // 16 lanes of a ds_read_b128 group hit 16 different units mod 16)
-constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed + 2 * 32 * kTwRow;   // + window rows, same shape
+constexpr int kLWords = kBlocks * 256;             // log-mel values of the finished tile, wave 0 -> wave 3: [block][lane * 4]
+constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed + 2 * 32 * kTwRow + kLWords;   // + window rows, same shape
 constexpr int kArole = 12;                        // per-wave role operands (fp32 MFMA A operands)
 
 // K slots of the two bf16 MFMAs of a lane: K index 8 q + i  <->  output m = kGrpM[grp][i] of lane group q
@@ -73,27 +86,32 @@ constexpr int kGrpM[2][8] = {{0, 1, 2, 3, 12, 13, 14, 15}, {4, 5, 6, 7, 8, 9, 10
 // (K group, filter block) sets of a variant.  Sets 0..2 are the same everywhere; what a sample rate adds is (Y, 1) (the
 // second block reaches past bin 256), (X, 2) (the third block starts below it) or both.
 template <int VAR> struct Sets;
+// c16[mb][blk]: the filter blocks that column 16's bins 16 + 32 j' reach, j' < 8 (mb = 0, bins 16..240) / j' >= 8 (mb = 1)
 template <> struct Sets<0> {                      // <= 22.05 kHz
     static constexpr int N = 4;
     static constexpr int grp[N] = {0, 0, 1, 1}, blk[N] = {0, 1, 2, 1};
+    static constexpr int c16[2][3] = {{1, 1, 0}, {0, 1, 1}};
 };
 template <> struct Sets<1> {                      // 44.1, 48 kHz
     static constexpr int N = 4;
     static constexpr int grp[N] = {0, 0, 1, 0}, blk[N] = {0, 1, 2, 2};
+    static constexpr int c16[2][3] = {{1, 1, 1}, {0, 0, 1}};
 };
 template <> struct Sets<2> {                      // 32 kHz
     static constexpr int N = 5;
     static constexpr int grp[N] = {0, 0, 1, 1, 0}, blk[N] = {0, 1, 2, 1, 2};
+    static constexpr int c16[2][3] = {{1, 1, 0}, {0, 0, 1}};
 };
 constexpr int kVariants = 3, kMaxSets = 5;
 struct SetsView {
     int n;
     const int *grp, *blk;
+    const int (*c16)[3];
 };
 inline SetsView sets_view(int v) {
-    if (v == 1) return {Sets<1>::N, Sets<1>::grp, Sets<1>::blk};
-    if (v == 2) return {Sets<2>::N, Sets<2>::grp, Sets<2>::blk};
-    return {Sets<0>::N, Sets<0>::grp, Sets<0>::blk};
+    if (v == 1) return {Sets<1>::N, Sets<1>::grp, Sets<1>::blk, Sets<1>::c16};
+    if (v == 2) return {Sets<2>::N, Sets<2>::grp, Sets<2>::blk, Sets<2>::c16};
+    return {Sets<0>::N, Sets<0>::grp, Sets<0>::blk, Sets<0>::c16};
 }
 
 using mfcc_fc::f32x4;
@@ -219,7 +237,7 @@ inline bool build_tables_for(int variant, int sample_rate, double power_scale, d
             for (int step = 0; step < 2; ++step)
                 for (int l = 0; l < 64; ++l) {
                     const int filt = blk * 16 + (l & 15), bin = 16 + 32 * (8 * mb + 2 * (l >> 4) + step);
-                    if (filt >= kMel) continue;
+                    if (filt >= kMel || !sv.c16[mb][blk]) continue;
                     R(wave, 4 + 2 * blk + step, l) = float(Wt(filt, bin));
                     covered[size_t(filt) * nb + bin] = 1;
                 }
@@ -316,17 +334,21 @@ __device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t &hi, 
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
 }
 
-// summed mel energies of a finished tile and their log2: register r of block b is filter 16 b + 4 q + r of frame j; the
-// partial sums of a frame lie in both column halves (lane and lane ^ 8) of four waves.  Filters 40..47 do not exist:
-// their (zero) sums must not reach the DCT as -inf * 0
+// summed mel energies of a finished tile and their log2: register r of block b is filter 16 b + 4 q + r of frame j (the
+// four waves' partial sums; each wave has already added its two column halves).  Filters 40..47 do not exist: their
+// (zero) sums must not reach the DCT as -inf * 0
 __device__ __forceinline__ void mel_log2(const float *Qt, int lane, int q, f32x4 (&lm)[kBlocks]) {
     const f32x4 *Qa = reinterpret_cast<const f32x4 *>(Qt) + lane;
+#if !F1K_PRESUM
     const f32x4 *Qb = reinterpret_cast<const f32x4 *>(Qt) + (lane ^ 8);
+#endif
 #pragma unroll
     for (int b = 0; b < kBlocks; ++b) {
-        f32x4 m = Qa[(0 * kBlocks + b) * 64] + Qb[(0 * kBlocks + b) * 64];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) m += Qa[(w * kBlocks + b) * 64] + Qb[(w * kBlocks + b) * 64];
+        f32x4 m = (Qa[(0 * kBlocks + b) * 64] + Qa[(1 * kBlocks + b) * 64]) +
+                  (Qa[(2 * kBlocks + b) * 64] + Qa[(3 * kBlocks + b) * 64]);
+#if !F1K_PRESUM
+        m += (Qb[(0 * kBlocks + b) * 64] + Qb[(1 * kBlocks + b) * 64]) + (Qb[(2 * kBlocks + b) * 64] + Qb[(3 * kBlocks + b) * 64]);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) lm[b][r] = __builtin_amdgcn_logf(m[r]);
     }
@@ -364,6 +386,23 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tab
     }
 }
 
+// Diagnostic build only (-DMFCC_F1K_STAMPS): per-wave cycle sums of the phases of a tile, written to a buffer of their
+// own that nothing else reads.  No stamp executes in the product build.
+#ifdef MFCC_F1K_STAMPS
+__device__ unsigned long long g_stamps1k[4 * 12 + 4];   // [wave][12 phases], then [48 + wave]: tiles
+#define F1K_STAMP(i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long now__;                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        st_sum[i] += now__ - st_prev;                                                         \
+        st_prev = now__;                                                                      \
+    } while (0)
+#else
+#define F1K_STAMP(i) do {} while (0)
+#endif
+
 template <int VAR>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *__restrict__ out) {
@@ -387,6 +426,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
     float *const Tw = Sf + kSUsed;                                 // [32 n2][36]: W1024^(n2 k1), k1 = 0..15
 
     float *const Wn = Tw + 32 * kTwRow;                            // [32 n2][36]: hamming[32 n1 + n2] / 64, n1 = 0..31
+    float *const Lt = Wn + 32 * kTwRow;                            // [3 blocks][256]: log-mel of the finished tile
     // window and twiddles are needed in pass 1 only: 64 registers of constants that every other phase would carry
     // around (with them resident the kernel spilled 23 VGPRs); 16 ds_read_b128 per lane and tile instead
     for (int i = tid; i < 32 * 32; i += 64 * kWaves) {
@@ -434,6 +474,11 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
     Cursor prev = cur;
     bool have_prev = false;
 
+#ifdef MFCC_F1K_STAMPS
+    unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+    unsigned long long st_tiles = 0;
+#endif
     while (cur.ch < g.n_ch) {
         // ---------------- pass 1: windowed real FFT-32 over n1 of the pre-emphasised samples
         v2f ep[16];
@@ -451,7 +496,21 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
             next_shift = wn.shift;
             fetch_window(s, wn, fetcher, fx);
         }
+        // The tail of the previous tile is split over the two waves without a column-16 job: wave 0 sums the partial mel
+        // energies and takes their log2 here and leaves them in LDS; wave 3 picks them up behind B1 for the DCT.  (With
+        // the whole tail on one wave the other three waited a third of every tile for it.)
+#if F1K_SPLIT_TAIL
+        if (wave == 0 && have_prev) {
+            if (F1K_TAIL_PRIO) __builtin_amdgcn_s_setprio(F1K_TAIL_PRIO);
+            mel_log2(Qt, lane, q, lm);
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) *reinterpret_cast<f32x4 *>(Lt + (b * 64 + lane) * 4) = lm[b];
+            if (F1K_TAIL_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+#else
         if (wave == 3 && have_prev) mel_log2(Qt, lane, q, lm);
+#endif
+        F1K_STAMP(0);
 
         v2f ty[16];
         float y16;
@@ -469,11 +528,14 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
             }
             mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
         }
+        F1K_STAMP(1);
         v2f *tcol0 = reinterpret_cast<v2f *>(Tt + fr_id * kTFrame) + n2;
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) tcol0[k1 * (kTRow / 2)] = ty[k1];
         Vt[fr_id * kVStride + n2] = y16;
+        F1K_STAMP(2);
         lds_barrier();                         // B1: T and V of all 8 frames are in LDS; S and Q are consumed
+        F1K_STAMP(3);
 
         // ---------------- pass 2: outputs k2 = 2 m + h of the complex FFT-32 over n2, frame j, column k1
         float pw[16];
@@ -488,11 +550,13 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
                 xh[2 * i] = (v2f){b[0], b[1]};
                 xh[2 * i + 1] = (v2f){b[2], b[3]};
             }
+            F1K_STAMP(4);
             if (h) mfcc_codelets::cfft32_h1(xl, xh, z);
             else mfcc_codelets::cfft32_h0(xl, xh, z);
 #pragma unroll
             for (int m = 0; m < 16; ++m) pw[m] = fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
         }
+        F1K_STAMP(5);
 
         // ---------------- the mel contraction (frame column = (j, sl), K index = q): both column halves' weights
         u32x4 ph[2], pl[2];
@@ -505,6 +569,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
                 ph[gk][d] = hi;
                 pl[gk][d] = lo;
             }
+        F1K_STAMP(6);
         f32x4 acc[2][NS];
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
@@ -530,6 +595,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
             for (int r = 0; r < 4; ++r) v[r] = sl ? acc[1][st][r] : acc[0][st][r];
             fin[S::blk[st]] += v;
         }
+        F1K_STAMP(7);
 
         if (wave == 1 || wave == 2) {
             // column 16 -> bins 16 + 32 j', j' = 8 mb + 2 q + {0, 1}: the column halves split n2 (sl = 1: n2 + 16)
@@ -547,30 +613,64 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
             // both halves now hold the frame's bins: only one of them may feed the filters
             const float c0 = sl ? 0.0f : fmaf(x0, x0, x1 * x1);
             const float c1 = sl ? 0.0f : fmaf(x2, x2, x3 * x3);
+            if (wave == 2) {
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) {
-                fin[b] = MFCC1K8_MFMA(ax[4 + 2 * b], c0, fin[b]);
-                fin[b] = MFCC1K8_MFMA(ax[5 + 2 * b], c1, fin[b]);
+                for (int b = 0; b < kBlocks; ++b)
+                    if (S::c16[0][b]) {
+                        fin[b] = MFCC1K8_MFMA(ax[4 + 2 * b], c0, fin[b]);
+                        fin[b] = MFCC1K8_MFMA(ax[5 + 2 * b], c1, fin[b]);
+                    }
+            } else {
+#pragma unroll
+                for (int b = 0; b < kBlocks; ++b)
+                    if (S::c16[1][b]) {
+                        fin[b] = MFCC1K8_MFMA(ax[4 + 2 * b], c0, fin[b]);
+                        fin[b] = MFCC1K8_MFMA(ax[5 + 2 * b], c1, fin[b]);
+                    }
             }
         }
         if (wave == 3 && have_prev) {
+            if (F1K_TAIL_PRIO) __builtin_amdgcn_s_setprio(F1K_TAIL_PRIO);
+#if F1K_SPLIT_TAIL
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) lm[b] = *reinterpret_cast<const f32x4 *>(Lt + (b * 64 + lane) * 4);
+#endif
             f32x4 d[kBlocks] = {zero, zero, zero};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int b = 0; b < kBlocks; ++b) d[b] = MFCC1K8_MFMA(ax[4 * b + r], lm[b][r], d[b]);
             dct_store(s, t, d, lm, prev, j, sl, q, lane, out);
+            if (F1K_TAIL_PRIO) __builtin_amdgcn_s_setprio(0);
         }
+        F1K_STAMP(8);
+        // a frame's sums lie in both column halves: add them here (one DPP add per register), so that the tail reads
+        // one lane's worth per wave
 #pragma unroll
-        for (int b = 0; b < kBlocks; ++b)
-            *reinterpret_cast<f32x4 *>(Qt + ((wave * kBlocks + b) * 64 + lane) * 4) = fin[b];
+        for (int b = 0; b < kBlocks; ++b) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = F1K_PRESUM ? fin[b][r] + other_half(fin[b][r]) : fin[b][r];
+            *reinterpret_cast<f32x4 *>(Qt + ((wave * kBlocks + b) * 64 + lane) * 4) = o;
+        }
         prev = me;
         have_prev = true;
         if (more) park_window(Sf, fetcher, fx);
         shift = next_shift;
+        F1K_STAMP(9);
         lds_barrier();                         // B2: partial sums and S are in LDS, T/V may be overwritten
+        F1K_STAMP(10);
+#ifdef MFCC_F1K_STAMPS
+        ++st_tiles;
+#endif
     }
-    if (wave == 3 && have_prev) {
+#ifdef MFCC_F1K_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps1k[wave * 12 + i], st_sum[i]);
+        atomicAdd(&g_stamps1k[48 + wave], st_tiles);
+    }
+#endif
+    if (wave == 3 && have_prev) {                  // the last tile's tail, whole
         mel_log2(Qt, lane, q, lm);
         f32x4 d[kBlocks] = {zero, zero, zero};
 #pragma unroll
@@ -588,7 +688,9 @@ inline bool launch(const mfcc_k::StreamDesc &s, const Tables &t, float *out, int
     const long long n_ch = s.total_frames / s.frames_per_ch;
     const long long n_tiles = tiles_per_ch * n_ch;
     if (n_tiles >= (1ll << 31) || tiles_per_ch >= (1ll << 26) || n_ch >= (1ll << 31)) return false;
-    long long grid = n_tiles < 2ll * n_cu ? n_tiles : 2ll * n_cu;      // two workgroups per CU (67 KB of LDS each)
+    long long per_cu = 2;                                              // two workgroups per CU (70 KB of LDS each)
+    if (const char *e = std::getenv("MFCC_HIP_F1K_GRID")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : 2;   // diagnostic
+    long long grid = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
     if (grid < 1) grid = 1;
     LaunchGeom g;
     g.tiles_per_ch = (int)tiles_per_ch;
