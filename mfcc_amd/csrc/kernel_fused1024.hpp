@@ -1,22 +1,37 @@
-// Fused 1024/341/40 float kernel for gfx950 (MI355X) -- BASELINE.json configs[3]: nfft 1024, hop
-// 1024//3 = 341 (mfcc/core/mfcc.py:43), 40 mel bands, n_cep <= 32, the mel contraction on the matrix
-// cores.  Same scheme as kernel_fused512.hpp (read its header first); what differs:
+// Fused 1024/341/40 float kernel for gfx950 (MI355X) -- BASELINE.json configs[3]: nfft 1024, hop 1024 // 3 = 341
+// (mfcc/core/mfcc.py:43), 40 mel bands, n_cep <= 40 (the reference tops keep nceptrums = nfilters), the mel contraction on
+// the matrix cores.  Same scheme as kernel_fused512.hpp (read its header first); what differs:
 //
-//  * a workgroup of EIGHT waves owns a tile of 16 consecutive frames, one workgroup per CU (118 KB of
-//    LDS: a 16-frame tile of 1024-point frames is twice the data);
-//  * pass 1: n = 32 n1 + n2.  Wave w, lane (f = lane >> 5, n2 = lane & 31) owns frame 2 w + f and runs
-//    the same register-resident REAL 32-point FFT over n1 (codelet rfft32_tw, Hamming folded in), twiddles
-//    columns 0..15 by W1024^(n2 k1) and writes T[frame][n2][k1]; column 16 (real) goes to V;
-//  * pass 2: the complex 32-point FFT over n2 of a column is split by ONE decimation-in-frequency step
-//    into its even and odd outputs, two lanes per column: wave w, lane (j = lane & 15, g = lane >> 4)
-//    takes column k1 = 4 (w >> 1) + g of frame j and the outputs k2 = 2 m + h, h = w & 1 (codelets
-//    cfft32_h0 / cfft32_h1: the DIF step, then a 16-point FFT).  X[k1 + 32 k2] is bin k1 + 32 k2 or, by
-//    the symmetry of a real signal, bin 1024 - (k1 + 32 k2): 512 lanes x 16 outputs = every bin once;
-//  * |X|^2 is again in the MFMA B-operand layout: the block-banded 40 x 513 mel matrix needs 17
-//    (h = 0) / 18 (h = 1) MFMAs per wave over three 16-filter blocks; partial sums meet in Q;
-//  * column 16 -> bins 16 + 32 j by a 32-point DFT matrix on the matrix cores, split over two waves
-//    (role 1: j = 0..7, role 2: j = 8..15; 8 MFMAs + their mel MFMAs each); role 0 finishes the
-//    previous tile (log2, DCT-II as 12 MFMAs, store) and neither fetches nor parks samples.
+//  * a workgroup of EIGHT waves owns a tile of 16 consecutive frames, one workgroup per CU (117 KB of LDS: a 16-frame tile
+//    of 1024-point frames is twice the data);
+//  * pass 1: n = 32 n1 + n2.  Wave w, lane (f = lane >> 5, n2 = lane & 31) owns frame 2 w + f and runs the same
+//    register-resident REAL 32-point FFT over n1 (codelet rfft32_tw, Hamming folded in), twiddles columns 0..15 by
+//    W1024^(n2 k1) and writes T[frame][k1][n2] -- the lanes of a store are consecutive n2; column 16 (real) goes to V;
+//  * pass 2: the complex 32-point FFT over n2 of a column is split by ONE decimation-in-frequency step into its even and
+//    odd outputs, two lanes per column: wave w, lane (j = lane & 15, q = lane >> 4) takes column k1 = 4 (w >> 1) + q of
+//    frame j and the outputs k2 = 2 m + h, h = w & 1 (codelets cfft32_h0 / cfft32_h1).  The column's 32 values are
+//    contiguous in T: 16 ds_read_b128 (256 B/clk; round 2 read T[frame][n2][k1] with 16 ds_read2_b64 at 128).
+//    X[k1 + 32 k2] is bin k1 + 32 k2 or, by the symmetry of a real signal, bin 1024 - (k1 + 32 k2): 512 lanes x 16 outputs =
+//    every bin once;
+//  * |X|^2 is again in the MFMA B-operand layout.  The mel contraction runs on v_mfma_f32_16x16x32_bf16 with both
+//    operands split in two bf16 terms (W = Wh + Wl, P = Ph + Pl; Wh Ph + Wh Pl + Wl Ph, fp32 accumulation, 2^-17
+//    relative): a lane's 16 outputs are two K groups of eight -- X = the eight lowest in frequency (m = 0..3, 12..15),
+//    Y = the rest -- and a wave issues one MFMA triple per (K group, 16-filter block) SET with non-zero weights: (X, 0),
+//    (X, 1), (Y, 2) at every sample rate, plus (Y, 1) [<= 22.05 kHz: the second block reaches past bin 256], (X, 2)
+//    [44.1 / 48 kHz: the third block starts below it] or both [32 kHz] -- THREE instantiations cover every common rate
+//    (round 2: five per-rate lists of 17-19 fp32 MFMAs of 32 clocks, during which the SIMD issues no vector instruction;
+//    44.1 / 48 kHz ran on the generic kernel, six times slower);
+//  * column 16 -> bins 16 + 32 j' by a 32-point DFT matrix on the fp32 matrix cores, split over two waves (role 1:
+//    j' = 0..7, role 2: j' = 8..15; 8 MFMAs + their mel MFMAs each); role 0 finishes the previous tile (log2, DCT-II as 12
+//    fp32 MFMAs per 16 coefficients, store) and neither fetches nor parks samples.
+//
+// This form serves every sample rate and coefficient count.  At the five rates round 2's fp32 lists exist for (8, 11.025, 16,
+// 22.05, 32 kHz) the handle takes kernel_fused1024_f32.hpp instead, which is 3 % faster there (A/B in one box session: in
+// these lockstep phases the bf16 split's 48 extra vector instructions per wave and tile cost more than the shorter matrix
+// instructions give back).  What else was built and measured this round, and dropped (profiles/r03_notes.md):
+// 8-frame tiles in two 4-wave workgroups per CU (every per-tile cost twice, MFMAs half empty: 260 vector instructions per
+// frame against 195, 9-13 % slower), and producer / consumer waves on the 16-frame tile (pass 1 of tile k + 1 in registers
+// beside pass 2 of tile k: the stores of T behind the barrier are an LDS-bound interval nothing overlaps, 12 % slower).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,13 +48,12 @@
 
 namespace mfcc_fused1024 {
 
-constexpr int kNfft = 1024, kHop = 341, kMel = 40, kMaxCep = 32;   // 32: what the reference tops keep (main.c:13)
+constexpr int kNfft = 1024, kHop = 341, kMel = 40, kMaxCep = 40;
 constexpr int kTile = 16, kWaves = 8;
 constexpr int kTileHop = kTile * kHop;            // 5456 samples between consecutive tiles
 constexpr int kTRow = 64;                         // words per k1 row of the transpose tile T[frame][k1][n2]: 32 complex
-constexpr int kTFrame = 16 * kTRow + 4;           // 1028 words per frame: pass 2 reads a column's 32 values -- contiguous --
-                                                  // with 16 ds_read_b128 (256 B/clk; round 2: T[frame][n2][k1], 16 ds_read2_b64 at
-                                                  // 128); (row, frame) strides of (16, 257) 16-byte units are conflict free
+constexpr int kTFrame = 16 * kTRow + 4;           // 1028 words per frame: (row, frame) strides of (16, 257) 16-byte units make
+                                                  // every ds_read_b128 of pass 2 conflict free (brute-forced over the lane groups)
 constexpr int kVStride = 34;                      // words per frame in the column-16 tile
 constexpr int kBlocks = 3;                        // 16-filter blocks of the 40 filters
 constexpr int kQWords = kWaves * kBlocks * 256;   // partial mel sums: [wave][block][lane * 4]
@@ -47,65 +61,43 @@ constexpr int kFetchers = 64 * (kWaves - 1);      // roles 1..7 fetch and park t
 constexpr int kPieces = (7 + (kTile - 1) * kHop + kNfft + 7) / 8;       // 769 pieces of 8 samples are read
 constexpr int kSecond = kPieces - kFetchers;      // fetchers that take a second piece (321)
 constexpr int kSUsed = 8 * kPieces;               // 6152 fp32 slots
-constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed;
+constexpr int kTwRow = 36;                        // words per n2 row of the twiddle table in LDS (9 16-byte units: the
+                                                  // 16 lanes of a ds_read_b128 group hit 16 different units mod 16)
+constexpr int kLdsWords = kTile * kTFrame + kTile * kVStride + kQWords + kSUsed + 32 * kTwRow;
+constexpr int kAextra = 14;                       // role operands: DCT rows (12) / column-16 DFT (8) + its mel weights (6)
 
-constexpr int kAmel = 19, kAextra = 12;
-// (output index m of the 16-point FFT, filter block) pairs with non-zero weights, per h = k2 & 1 -- the SCHEDULE of a
-// sample rate: where the three 16-filter blocks lie over the bins.  The MFMA sequences are compile-time (register
-// arrays), so every supported rate has its own instantiation; build_tables picks the first schedule that covers the
-// rate's matrix (and verifies it against the matrix itself).  16 kHz is the reference's rate and BASELINE's config 4;
-// 8 / 11.025 / 22.05 kHz need the same 17 + 18 operand registers in a different order, 32 kHz 19 + 16 (generated by
-// the same scan of the matrix that build_tables verifies: every (m, block) any wave of the parity has weight on,
-// ascending).  44.1 / 48 kHz put weight on the DC bin: generic kernel.
-// special column, role 1 (bins 16 + 32 j, j = 2 g + step, g = 0..3): (step, block); role 2: j = 8 + 2 g + step
-template <int R> struct Sched;
-template <> struct Sched<0> {
-    static constexpr int rate = 16000, N0 = 17, N1 = 18, NS1 = 4, NS2 = 3;
-    static constexpr int M0[kAmel] = {0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 0}, B0[kAmel] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0, 0, 0};
-    static constexpr int M1[kAmel] = {0, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 14, 15, 0}, B1[kAmel] = {0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 2, 1, 1, 1, 0, 0};
-    static constexpr int S1step[4] = {0, 0, 1, 1}, S1blk[4] = {0, 1, 0, 1};
-    static constexpr int S2step[4] = {0, 0, 1, 0}, S2blk[4] = {1, 2, 2, 0};
+// K slots of the two bf16 MFMAs of a lane: K index 8 q + i  <->  output m = kGrpM[grp][i] of lane group q
+constexpr int kGrpM[2][8] = {{0, 1, 2, 3, 12, 13, 14, 15}, {4, 5, 6, 7, 8, 9, 10, 11}};
+
+// (K group, filter block) sets of a variant; c16[mb][blk]: the filter blocks that column 16's bins 16 + 32 j' reach,
+// j' < 8 (mb = 0, bins 16..240) / j' >= 8 (mb = 1, bins 272..496).  build_tables picks the first variant that covers the
+// rate's matrix (and verifies it against the matrix itself).
+template <int VAR> struct Sets;
+template <> struct Sets<0> {                      // <= 22.05 kHz (16 kHz: the reference's rate and BASELINE's config 4)
+    static constexpr int N = 4;
+    static constexpr int grp[N] = {0, 0, 1, 1}, blk[N] = {0, 1, 2, 1};
+    static constexpr int c16[2][3] = {{1, 1, 0}, {0, 1, 1}};
 };
-template <> struct Sched<1> {
-    static constexpr int rate = 8000, N0 = 18, N1 = 17, NS1 = 4, NS2 = 4;
-    static constexpr int M0[kAmel] = {0, 1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 14, 15, 0}, B0[kAmel] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 1, 2, 1, 1, 1, 0, 0};
-    static constexpr int M1[kAmel] = {0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 0}, B1[kAmel] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0};
-    static constexpr int S1step[4] = {0, 0, 1, 1}, S1blk[4] = {0, 1, 0, 1};
-    static constexpr int S2step[4] = {0, 0, 1, 1}, S2blk[4] = {1, 2, 1, 2};
+template <> struct Sets<1> {                      // 44.1, 48 kHz
+    static constexpr int N = 4;
+    static constexpr int grp[N] = {0, 0, 1, 0}, blk[N] = {0, 1, 2, 2};
+    static constexpr int c16[2][3] = {{1, 1, 1}, {0, 0, 1}};
 };
-template <> struct Sched<2> {
-    static constexpr int rate = 11025, N0 = 17, N1 = 18, NS1 = 4, NS2 = 4;
-    static constexpr int M0[kAmel] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 14, 15, 0, 0}, B0[kAmel] = {0, 0, 1, 1, 1, 2, 2, 2, 2, 2, 2, 1, 2, 1, 1, 1, 0, 0, 0};
-    static constexpr int M1[kAmel] = {0, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 14, 15, 0}, B1[kAmel] = {0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0, 1, 0, 0};
-    static constexpr int S1step[4] = {0, 0, 1, 1}, S1blk[4] = {0, 1, 0, 1};
-    static constexpr int S2step[4] = {0, 0, 1, 1}, S2blk[4] = {1, 2, 1, 2};
+template <> struct Sets<2> {                      // 32 kHz
+    static constexpr int N = 5;
+    static constexpr int grp[N] = {0, 0, 1, 1, 0}, blk[N] = {0, 1, 2, 1, 2};
+    static constexpr int c16[2][3] = {{1, 1, 0}, {0, 0, 1}};
 };
-template <> struct Sched<3> {
-    static constexpr int rate = 22050, N0 = 18, N1 = 17, NS1 = 4, NS2 = 3;
-    static constexpr int M0[kAmel] = {0, 1, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0}, B0[kAmel] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0, 0};
-    static constexpr int M1[kAmel] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 12, 13, 14, 15, 0, 0}, B1[kAmel] = {0, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 2, 1, 1, 1, 0, 0, 0};
-    static constexpr int S1step[4] = {0, 0, 1, 1}, S1blk[4] = {0, 1, 0, 1};
-    static constexpr int S2step[4] = {0, 0, 1, 0}, S2blk[4] = {1, 2, 2, 0};
+constexpr int kVariants = 3;
+struct SetsView {
+    int n;
+    const int *grp, *blk;
+    const int (*c16)[3];
 };
-template <> struct Sched<4> {
-    static constexpr int rate = 32000, N0 = 19, N1 = 16, NS1 = 4, NS2 = 2;
-    static constexpr int M0[kAmel] = {0, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 12, 13, 14, 15, 15}, B0[kAmel] = {0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 2, 1, 1, 0, 1};
-    static constexpr int M1[kAmel] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 0, 0}, B1[kAmel] = {0, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0};
-    static constexpr int S1step[4] = {0, 0, 1, 1}, S1blk[4] = {0, 1, 0, 1};
-    static constexpr int S2step[4] = {0, 1, 0, 0}, S2blk[4] = {2, 2, 0, 0};
-};
-constexpr int kSchedules = 5;
-// the same lists for the host's table builder
-struct SchedView {
-    int n0, n1, ns1, ns2;
-    const int *m0, *b0, *m1, *b1, *s1step, *s1blk, *s2step, *s2blk;
-};
-template <int R> inline SchedView sched_view() {
-    using S = Sched<R>;
-    return {S::N0, S::N1, S::NS1, S::NS2, S::M0, S::B0, S::M1, S::B1, S::S1step, S::S1blk, S::S2step, S::S2blk};
-}
-inline SchedView sched_view(int r) {
-    return r == 1 ? sched_view<1>() : r == 2 ? sched_view<2>() : r == 3 ? sched_view<3>() : r == 4 ? sched_view<4>() : sched_view<0>();
+inline SetsView sets_view(int v) {
+    if (v == 1) return {Sets<1>::N, Sets<1>::grp, Sets<1>::blk, Sets<1>::c16};
+    if (v == 2) return {Sets<2>::N, Sets<2>::grp, Sets<2>::blk, Sets<2>::c16};
+    return {Sets<0>::N, Sets<0>::grp, Sets<0>::blk, Sets<0>::c16};
 }
 
 using mfcc_fc::f32x4;
@@ -118,15 +110,17 @@ using mfcc_fc::window_of;
 using mfcc_fc::preemph8;
 using mfcc_fc::lds_barrier;
 using mfcc_codelets::v2f;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Tables {
-    int sched;             // which Sched<R> the operand tables were laid out for
+    int variant;           // which Sets<VAR> the operand tables were laid out for
     const float *win;      // [32 n2][32 n1]  hamming[32 n1 + n2] / 64
     const float *tw;       // [32 n2][16 k1][2] W1024^(n2 k1)
-    const float *a_mel;    // [8 waves][kAmel][64]
-    const float *a_extra;  // [3 roles][12][64]  role 0: DCT rows; role 1 / 2: column-16 DFT (8) + its mel weights;
-                           // then [12][64]: DCT rows of coefficients 16..31 (fetched per tile, only when n_cep > 16: the
-                           // kernel has no registers left to keep them)
+    const uint32_t *a_bf;  // [8 waves][sets][hi, lo][4 dwords][64 lanes] mel weights as bf16 pairs
+    const float *a_extra;  // [3 roles][kAextra][64]  role 0: DCT rows 0..15; role 1 / 2: column-16 DFT (8) + its mel weights (6)
+    const float *a_dct_hi; // [2][12][64]  DCT rows of coefficients 16..31 and 32..47 (fetched per tile, only when n_cep > 16:
+                           // the kernel has no registers to keep them)
     int n_cep;
 };
 
@@ -142,11 +136,11 @@ inline int bin_of(int k1, int h, int m) {
     return 32 * (32 - k2) - k1;
 }
 
-inline bool build_tables_for(const SchedView &sv, int sample_rate, double power_scale, double lifter, int n_cep,
+inline bool build_tables_for(int variant, int sample_rate, double power_scale, double lifter, int n_cep,
                              std::vector<char> &blob) {
     using namespace mfcc_tables;
-    std::vector<float> win(32 * 32), tw(32 * 16 * 2), amel(size_t(kWaves) * kAmel * 64, 0.0f),
-        aext(size_t(4) * kAextra * 64, 0.0f);
+    const SetsView sv = sets_view(variant);
+    std::vector<float> win(32 * 32), tw(32 * 16 * 2), aext(size_t(3) * kAextra * 64, 0.0f), adct(size_t(2) * 12 * 64, 0.0f);
     std::vector<double> w = hamming_periodic(kNfft);
     for (int n2 = 0; n2 < 32; ++n2)
         for (int n1 = 0; n1 < 32; ++n1) win[n2 * 32 + n1] = float(w[32 * n1 + n2] / 64.0);
@@ -159,89 +153,120 @@ inline bool build_tables_for(const SchedView &sv, int sample_rate, double power_
     const int nb = kNfft / 2 + 1;                                             // 513
     std::vector<double> md = mel_dense(kNfft, kMel, double(sample_rate));     // [40][513]
     for (int f = 0; f < kMel; ++f)
-        if (md[size_t(f) * nb] != 0.0) return false;      // weight on the DC bin: the generic kernel sums it in double
+        if (md[size_t(f) * nb] != 0.0) return false;      // weight on the real-valued DC bin: not summed in fp32;
+                                                          // no common rate has it at 1024 points / 40 filters
     const double inv = 1.0 / (power_scale * power_scale);
     std::vector<char> covered(size_t(kMel) * nb, 0);
     auto Wt = [&](int filt, int bin) -> double { return filt < kMel ? md[size_t(filt) * nb + bin] * inv : 0.0; };
-    for (int wv = 0; wv < kWaves; ++wv) {
-        const int h = wv & 1, n = h ? sv.n1 : sv.n0;
-        for (int idx = 0; idx < n; ++idx) {
-            const int m = h ? sv.m1[idx] : sv.m0[idx], blk = h ? sv.b1[idx] : sv.b0[idx];
+    auto bf16_round = [](float v) -> uint32_t {                              // round to nearest even, like v_cvt_pk_bf16_f32
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    auto bf16_val = [](uint32_t h) -> float {
+        uint32_t u = h << 16;
+        float v;
+        std::memcpy(&v, &u, 4);
+        return v;
+    };
+    // mel operands: lane l of wave wv, set st holds rows l & 15 of filter block blk[st] at K slots i = 0..7
+    // <-> bin(k1 = 4 (wv >> 1) + (l >> 4), h = wv & 1, m = kGrpM[grp[st]][i]); dword d = slots (2 d, 2 d + 1)
+    std::vector<uint32_t> abf(size_t(kWaves) * sv.n * 2 * 4 * 64, 0u);
+    for (int wv = 0; wv < kWaves; ++wv)
+        for (int st = 0; st < sv.n; ++st)
             for (int l = 0; l < 64; ++l) {
-                const int filt = blk * 16 + (l & 15), k1 = 4 * (wv >> 1) + (l >> 4);
-                const int bin = bin_of(k1, h, m);
-                if (bin < 0 || filt >= kMel) continue;
-                amel[(size_t(wv) * kAmel + idx) * 64 + l] = float(Wt(filt, bin));
-                covered[size_t(filt) * nb + bin] = 1;
+                uint32_t hi[8], lo[8];
+                for (int i = 0; i < 8; ++i) {
+                    const int filt = sv.blk[st] * 16 + (l & 15), k1 = 4 * (wv >> 1) + (l >> 4);
+                    const int bin = bin_of(k1, wv & 1, kGrpM[sv.grp[st]][i]);
+                    float wgt = 0.0f;
+                    if (bin >= 0 && filt < kMel) {
+                        wgt = float(Wt(filt, bin));
+                        covered[size_t(filt) * nb + bin] = 1;
+                    }
+                    hi[i] = bf16_round(wgt);
+                    lo[i] = bf16_round(wgt - bf16_val(hi[i]));
+                }
+                const size_t base = (size_t(wv) * sv.n + st) * 2 * 256;
+                for (int d = 0; d < 4; ++d) {
+                    abf[base + 0 * 256 + d * 64 + l] = hi[2 * d] | (hi[2 * d + 1] << 16);
+                    abf[base + 1 * 256 + d * 64 + l] = lo[2 * d] | (lo[2 * d + 1] << 16);
+                }
             }
-        }
-    }
     auto E = [&](int role, int idx, int lane) -> float & { return aext[(size_t(role) * kAextra + idx) * 64 + lane]; };
-    // role 0 -- DCT rows: lane (coeff = l & 15, g = l >> 4) holds D[coeff][16 blk + 4 g + r]
+    // role 0 -- DCT rows: lane (coeff = l & 15, g = l >> 4) holds D[16 tile + coeff][16 blk + 4 g + r]
     std::vector<double> dd = dct_rows(n_cep, kMel, lifter);                   // [n_cep][40]
-    for (int blk = 0; blk < kBlocks; ++blk)
-        for (int r = 0; r < 4; ++r)
-            for (int l = 0; l < 64; ++l) {
-                const int coeff = l & 15, filt = 16 * blk + 4 * (l >> 4) + r;
-                E(0, 4 * blk + r, l) = (coeff < n_cep && filt < kMel) ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
-                E(3, 4 * blk + r, l) = (16 + coeff < n_cep && filt < kMel) ? float(dd[size_t(16 + coeff) * kMel + filt]) : 0.0f;
-            }
-    // roles 1, 2 -- column 16: X[16 + 32 j] = sum_n2 v[n2] W1024^(n2 (16 + 32 j)); MFMA row i = 4 g + r holds
-    // r = 0: Re j = jb + 2 g, r = 1: Im (same j), r = 2: Re j + 1, r = 3: Im; K step t covers n2 = 4 t + (l >> 4)
+    for (int tile = 0; tile < 3; ++tile)
+        for (int blk = 0; blk < kBlocks; ++blk)
+            for (int r = 0; r < 4; ++r)
+                for (int l = 0; l < 64; ++l) {
+                    const int coeff = 16 * tile + (l & 15), filt = 16 * blk + 4 * (l >> 4) + r;
+                    const float v = (coeff < n_cep && filt < kMel) ? float(dd[size_t(coeff) * kMel + filt]) : 0.0f;
+                    if (tile == 0) E(0, 4 * blk + r, l) = v;
+                    else adct[(size_t(tile - 1) * 12 + 4 * blk + r) * 64 + l] = v;
+                }
+    // roles 1, 2 -- column 16: X[16 + 32 j'] = sum_n2 v[n2] W1024^(n2 (16 + 32 j')), j' = 8 (role - 1) + 0..7; MFMA row
+    // i = 4 g + r holds r = 0: Re j' = jb + 2 g, r = 1: Im (same j'), r = 2: Re j' + 1, r = 3: Im; K step t covers n2 = 4 t + (l >> 4)
     for (int role = 1; role <= 2; ++role) {
-        const int jb = role == 1 ? 0 : 8;
+        const int mb = role - 1;
         for (int t = 0; t < 8; ++t)
             for (int l = 0; l < 64; ++l) {
                 const int i = l & 15, n2 = 4 * t + (l >> 4);
-                const int g = i >> 2, r = i & 3, j = jb + 2 * g + (r >> 1);
-                const double th = 2.0 * kPi * double(n2 * (16 + 32 * j)) / 1024.0;
+                const int g = i >> 2, r = i & 3, jp = 8 * mb + 2 * g + (r >> 1);
+                const double th = 2.0 * kPi * double(n2 * (16 + 32 * jp)) / 1024.0;
                 E(role, t, l) = float((r & 1) ? -std::sin(th) : std::cos(th));
             }
-        // its bins as K steps: lane g supplies bin 16 + 32 (jb + 2 g + step)
-        const int ns = role == 1 ? sv.ns1 : sv.ns2;
-        for (int idx = 0; idx < ns; ++idx) {
-            const int step = role == 1 ? sv.s1step[idx] : sv.s2step[idx], blk = role == 1 ? sv.s1blk[idx] : sv.s2blk[idx];
-            for (int l = 0; l < 64; ++l) {
-                const int filt = blk * 16 + (l & 15), bin = 16 + 32 * (jb + 2 * (l >> 4) + step);
-                if (filt >= kMel) continue;
-                E(role, 8 + idx, l) = float(Wt(filt, bin));
-                covered[size_t(filt) * nb + bin] = 1;
-            }
-        }
+        // its bins as K steps of fp32 MFMAs: lane group q supplies bin 16 + 32 (8 mb + 2 q + step) to block blk
+        for (int blk = 0; blk < kBlocks; ++blk)
+            for (int step = 0; step < 2; ++step)
+                for (int l = 0; l < 64; ++l) {
+                    const int filt = blk * 16 + (l & 15), bin = 16 + 32 * (8 * mb + 2 * (l >> 4) + step);
+                    if (filt >= kMel || !sv.c16[mb][blk]) continue;
+                    E(role, 8 + 2 * blk + step, l) = float(Wt(filt, bin));
+                    covered[size_t(filt) * nb + bin] = 1;
+                }
     }
     for (int f = 0; f < kMel; ++f)
         for (int k = 0; k < nb; ++k)
             if (md[size_t(f) * nb + k] != 0.0 && !covered[size_t(f) * nb + k]) return false;
-    auto put = [&](const std::vector<float> &v) {
+    auto put = [&](const void *p, size_t bytes) {
         size_t off = blob.size();
-        blob.resize(off + v.size() * 4);
-        std::memcpy(blob.data() + off, v.data(), v.size() * 4);
+        blob.resize(off + bytes);
+        std::memcpy(blob.data() + off, p, bytes);
     };
     blob.clear();
-    put(win); put(tw); put(amel); put(aext);
+    put(win.data(), win.size() * 4);
+    put(tw.data(), tw.size() * 4);
+    put(aext.data(), aext.size() * 4);
+    put(adct.data(), adct.size() * 4);
+    put(abf.data(), abf.size() * 4);
     return true;
 }
 
-// the first schedule that covers the rate's filterbank (build_tables_for checks every non-zero weight)
-inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep, std::vector<char> &blob, int &sched) {
-    for (sched = 0; sched < kSchedules; ++sched)
-        if (build_tables_for(sched_view(sched), sample_rate, power_scale, lifter, n_cep, blob)) return true;
+// the first variant whose sets cover the rate's filterbank (build_tables_for checks every non-zero weight)
+inline bool build_tables(int sample_rate, double power_scale, double lifter, int n_cep, std::vector<char> &blob, int &variant) {
+    for (variant = 0; variant < kVariants; ++variant)
+        if (build_tables_for(variant, sample_rate, power_scale, lifter, n_cep, blob)) return true;
     return false;
 }
 
-inline void bind_tables(const char *b, int n_cep, int sched, Tables &t) {
-    t.sched = sched;
+inline void bind_tables(const char *b, int n_cep, int variant, Tables &t) {
+    t.variant = variant;
     t.n_cep = n_cep;
     const float *f = reinterpret_cast<const float *>(b);
-    t.win = f;      f += 32 * 32;
-    t.tw = f;       f += 32 * 16 * 2;
-    t.a_mel = f;    f += kWaves * kAmel * 64;
-    t.a_extra = f;
+    t.win = f;        f += 32 * 32;
+    t.tw = f;         f += 32 * 16 * 2;
+    t.a_extra = f;    f += 3 * kAextra * 64;
+    t.a_dct_hi = f;   f += 2 * 12 * 64;
+    t.a_bf = reinterpret_cast<const uint32_t *>(f);
 }
 
 // ---- device (helpers shared in spirit with kernel_fused512.hpp; kept local so the two kernels stay independent)
 
 #define MFCC1K_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFCC1K_MFMA_BF(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 struct Fetch {
     i32x4 v0, v1;
@@ -282,6 +307,13 @@ __device__ __forceinline__ void park_window(float *Sf, int u, const Fetch &f) {
     if (u < kSecond) preemph8(f.p1, f.v1, Sf + 8 * (kFetchers + u));
 }
 
+// (a, b) -> their bf16 roundings packed in one dword (a low) and the bf16 roundings of what the first rounding lost
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t &hi, uint32_t &lo) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
+}
+
 // summed mel energies of a finished tile and their log2; register r of block b is filter 16 b + 4 q + r of
 // frame lo.  Filters 40..47 do not exist: their (zero) sums must not reach the DCT as -inf * 0
 __device__ __forceinline__ void mel_log2(const float *Qt, int lane, int q, f32x4 (&lm)[kBlocks]) {
@@ -297,22 +329,22 @@ __device__ __forceinline__ void mel_log2(const float *Qt, int lane, int q, f32x4
     if (q >= 2) lm[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// d[0] + d[1] + d[2] = the DCT of the previous tile (its 12 MFMAs are issued by the caller); coefficients 16..31 are a
-// second M tile whose A operands are fetched here (uniform branch; 12 coalesced dwords per lane out of L1 / L2)
+// d[0] + d[1] + d[2] = coefficients 0..15 of the previous tile (their 12 MFMAs are issued by the caller); 16..31 and
+// 32..39 are further M tiles whose A operands are fetched here (uniform branches; 12 coalesced dwords per lane out of L2)
 __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tables &t, const f32x4 (&d)[kBlocks],
                                           const f32x4 (&lm)[kBlocks], const Cursor &c, int lo, int q, int lane,
                                           int lane_off, float *__restrict__ out) {
-    const f32x4 d0 = d[0], d1 = d[1], d2 = d[2];
     const long long fr0 = (long long)c.t_in * kTile;
     const long long rows_left = s.frames_per_ch - fr0;
     float *o = out + ((long long)c.ch * s.frames_per_ch + fr0) * t.n_cep + lane_off;
-    if (lo < rows_left) {
+    const bool mine = lo < rows_left;
+    if (mine) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * q + r < t.n_cep) o[r] = (d0[r] + d1[r]) + d2[r];
+            if (4 * q + r < t.n_cep) o[r] = (d[0][r] + d[1][r]) + d[2][r];
     }
-    if (t.n_cep > 16) {
-        const float *hi = t.a_extra + (size_t)3 * kAextra * 64 + lane;
+    for (int tile = 1; 16 * tile < t.n_cep; ++tile) {
+        const float *hi = t.a_dct_hi + (size_t)(tile - 1) * 12 * 64 + lane;
         asm volatile("" : "+v"(hi));                   // not hoisted out of the tile loop: no registers to hold it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 e[kBlocks] = {zero, zero, zero};
@@ -320,47 +352,19 @@ __device__ __forceinline__ void dct_store(const mfcc_k::StreamDesc &s, const Tab
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int b = 0; b < kBlocks; ++b) e[b] = MFCC1K_MFMA(hi[(4 * b + r) * 64], lm[b][r], e[b]);
-        if (lo < rows_left) {
+        if (mine) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (16 + 4 * q + r < t.n_cep) o[16 + r] = (e[0][r] + e[1][r]) + e[2][r];
+                if (16 * tile + 4 * q + r < t.n_cep) o[16 * tile + r] = (e[0][r] + e[1][r]) + e[2][r];
         }
     }
 }
 
-// role 0 (wave 0, h = 0): this tile's 17 mel MFMAs and the previous tile's 12 DCT MFMAs in one basic block,
-// interleaved -- six independent accumulator chains instead of two long tails
-template <int R>
-__device__ __forceinline__ void mel_dct_mfmas(const float (&pw)[16], const float (&am)[kAmel], const float (&ax)[kAextra],
-                                              const f32x4 (&lm)[kBlocks], f32x4 (&acc)[kBlocks], f32x4 (&d)[kBlocks]) {
-    using S = Sched<R>;
-    static_assert(S::N0 >= 12, "the DCT's 12 MFMAs ride on the mel chain");
-#pragma unroll
-    for (int i = 0; i < S::N0; ++i) {
-        acc[S::B0[i]] = MFCC1K_MFMA(am[i], pw[S::M0[i]], acc[S::B0[i]]);
-        if (i < 12) d[i % 3] = MFCC1K_MFMA(ax[4 * (i % 3) + i / 3], lm[i % 3][i / 3], d[i % 3]);
-    }
-}
-
-// mel MFMAs of one wave: template on h so that each wave's list is compile-time
-template <int R, int H>
-__device__ __forceinline__ void mel_mfmas(const float (&pw)[16], const float (&am)[kAmel], f32x4 (&acc)[kBlocks]) {
-    using S = Sched<R>;
-    constexpr int n = H ? S::N1 : S::N0;
-#ifdef F1K_T16_NOMEL          // timing experiment only (wrong results): what the mel MFMAs cost
-    acc[0][0] += pw[0] + pw[5] + pw[9] + pw[15] + am[3];
-#else
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-        const int m = H ? S::M1[i] : S::M0[i], b = H ? S::B1[i] : S::B0[i];
-        acc[b] = MFCC1K_MFMA(am[i], pw[m], acc[b]);
-    }
-#endif
-}
-
-template <int R>
+template <int VAR>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *__restrict__ out) {
+    using S = Sets<VAR>;
+    constexpr int NS = S::N;
     __shared__ __attribute__((aligned(16))) float lds[kLdsWords];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -368,11 +372,11 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
     const int role = wave;
     const int h = wave & 1;
     const int lo = lane & 15;          // frame column in pass 2 and the MFMA window
-    const int q = lane >> 4;           // column offset g in pass 2; K index in the MFMA window
+    const int q = lane >> 4;           // column offset in pass 2; K index in the MFMA window
     const int n2 = lane & 31;          // pass 1
     const int fr_id = 2 * wave + (lane >> 5);
 
-    float *const Tt = lds;                                         // [16 frames][1090]: [32 n2][34] each
+    float *const Tt = lds;                                         // [16 frames][1028]: [16 k1][64] each
     float *const Vt = Tt + kTile * kTFrame;                        // [16 frames][34]
     float *const Qt = Vt + kTile * kVStride;                       // [8 waves][3 blocks][256]
     float *const Sf = Qt + kQWords;                                // pre-emphasised sample window, fp32
@@ -380,12 +384,20 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
     v2f wp[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) wp[i] = reinterpret_cast<const v2f *>(t.win)[n2 * 16 + i];
-    v2f tw[16];
+    // the twiddles are needed at the end of pass 1 only: 32 registers of constants that every other phase would carry
+    // around (with them resident the kernel spilled 16 VGPRs); 8 ds_read_b128 per lane and tile instead
+    float *const Tw = Sf + kSUsed;                                 // [32 n2][36]: W1024^(n2 k1), k1 = 0..15
+    for (int i = tid; i < 32 * 32; i += 64 * kWaves) Tw[(i >> 5) * kTwRow + (i & 31)] = t.tw[i];
+    u32x4 ah[NS], al[NS];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tw[i] = reinterpret_cast<const v2f *>(t.tw)[n2 * 16 + i];
-    float am[kAmel], ax[kAextra];
+    for (int st = 0; st < NS; ++st)
 #pragma unroll
-    for (int i = 0; i < kAmel; ++i) am[i] = t.a_mel[(wave * kAmel + i) * 64 + lane];
+        for (int d = 0; d < 4; ++d) {
+            const size_t base = ((size_t)wave * NS + st) * 2 * 256;
+            ah[st][d] = t.a_bf[base + 0 * 256 + d * 64 + lane];
+            al[st][d] = t.a_bf[base + 1 * 256 + d * 64 + lane];
+        }
+    float ax[kAextra];
 #pragma unroll
     for (int i = 0; i < kAextra; ++i) ax[i] = role < 3 ? t.a_extra[(role * kAextra + i) * 64 + lane] : 0.0f;
 
@@ -439,7 +451,17 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
 
         v2f ty[16];
         float y16;
-        mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
+        {
+            v2f tw[16];
+            const f32x4 *twr = reinterpret_cast<const f32x4 *>(Tw + n2 * kTwRow);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 v = twr[i];
+                tw[2 * i] = (v2f){v[0], v[1]};
+                tw[2 * i + 1] = (v2f){v[2], v[3]};
+            }
+            mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
+        }
 
         v2f *tcol0 = reinterpret_cast<v2f *>(Tt + fr_id * kTFrame) + n2;      // a store's lanes are consecutive n2
 #pragma unroll
@@ -466,41 +488,69 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
             for (int m = 0; m < 16; ++m) pw[m] = fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
         }
 
-        // ---------------- MFMA window (frame column = lo, K index = q)
-        f32x4 acc[kBlocks] = {zero, zero, zero};
+        // ---------------- MFMA window (frame column = lo, K index = q): the mel contraction on bf16 pairs
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t hi, lw;
+                split_bf16_pair(pw[kGrpM[gk][2 * d]], pw[kGrpM[gk][2 * d + 1]], hi, lw);
+                ph[gk][d] = hi;
+                pl[gk][d] = lw;
+            }
+        f32x4 acc[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) acc[st] = zero;
+        f32x4 d[kBlocks] = {zero, zero, zero};
+        // term-major: consecutive MFMAs never share an accumulator; role 0 rides the previous tile's 12 DCT MFMAs (fp32)
+        // on the chain, one behind each of the first twelve
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const u32x4 &a = term == 2 ? al[st] : ah[st];
+                const u32x4 &b = term == 1 ? pl[S::grp[st]] : ph[S::grp[st]];
+                acc[st] = MFCC1K_MFMA_BF(a, b, acc[st]);
+                const int i = term * NS + st;
+                if (role == 0 && i < 12) d[i % 3] = MFCC1K_MFMA(ax[4 * (i % 3) + i / 3], lm[i % 3][i / 3], d[i % 3]);
+            }
+        f32x4 fin[kBlocks] = {zero, zero, zero};
+#pragma unroll
+        for (int st = 0; st < NS; ++st) fin[S::blk[st]] += acc[st];
+
         if (role == 1 || role == 2) {
-            // column 16 -> bins 16 + 32 j, j = jb + 2 q + {0, 1}, fed to the filter blocks from registers
+            // column 16 -> bins 16 + 32 j', j' = 8 (role - 1) + 2 q + {0, 1}, fed to the filter blocks from registers
+            const float *vp = Vt + lo * kVStride + q;
             f32x4 sp = zero, sp2 = zero;
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
-                sp = MFCC1K_MFMA(ax[k], Vt[lo * kVStride + 4 * k + q], sp);
-                sp2 = MFCC1K_MFMA(ax[k + 1], Vt[lo * kVStride + 4 * (k + 1) + q], sp2);
+                sp = MFCC1K_MFMA(ax[k], vp[4 * k], sp);
+                sp2 = MFCC1K_MFMA(ax[k + 1], vp[4 * (k + 1)], sp2);
             }
             sp += sp2;
-            const float s0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);
-            const float s1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);
+            const float c0 = fmaf(sp[0], sp[0], sp[1] * sp[1]);
+            const float c1 = fmaf(sp[2], sp[2], sp[3] * sp[3]);
             if (role == 1) {
 #pragma unroll
-                for (int i = 0; i < Sched<R>::NS1; ++i)
-                    acc[Sched<R>::S1blk[i]] = MFCC1K_MFMA(ax[8 + i], Sched<R>::S1step[i] ? s1 : s0, acc[Sched<R>::S1blk[i]]);
+                for (int b = 0; b < kBlocks; ++b)
+                    if (S::c16[0][b]) {
+                        fin[b] = MFCC1K_MFMA(ax[8 + 2 * b], c0, fin[b]);
+                        fin[b] = MFCC1K_MFMA(ax[9 + 2 * b], c1, fin[b]);
+                    }
             } else {
 #pragma unroll
-                for (int i = 0; i < Sched<R>::NS2; ++i)
-                    acc[Sched<R>::S2blk[i]] = MFCC1K_MFMA(ax[8 + i], Sched<R>::S2step[i] ? s1 : s0, acc[Sched<R>::S2blk[i]]);
+                for (int b = 0; b < kBlocks; ++b)
+                    if (S::c16[1][b]) {
+                        fin[b] = MFCC1K_MFMA(ax[8 + 2 * b], c0, fin[b]);
+                        fin[b] = MFCC1K_MFMA(ax[9 + 2 * b], c1, fin[b]);
+                    }
             }
         }
-        if (role == 0) {
-            f32x4 d[kBlocks] = {zero, zero, zero};
-            mel_dct_mfmas<R>(pw, am, ax, lm, acc, d);           // lm = 0 before the first tile
-            if (have_prev) dct_store(s, t, d, lm, prev, lo, q, lane, lane_off, out);
-        } else if (h) {
-            mel_mfmas<R, 1>(pw, am, acc);
-        } else {
-            mel_mfmas<R, 0>(pw, am, acc);
-        }
+        if (role == 0 && have_prev) dct_store(s, t, d, lm, prev, lo, q, lane, lane_off, out);
 #pragma unroll
         for (int b = 0; b < kBlocks; ++b)
-            *reinterpret_cast<f32x4 *>(Qt + ((wave * kBlocks + b) * 64 + lane) * 4) = acc[b];
+            *reinterpret_cast<f32x4 *>(Qt + ((wave * kBlocks + b) * 64 + lane) * 4) = fin[b];
         prev = me;
         have_prev = true;
         if (more && role != 0) park_window(Sf, fetcher, fx);
@@ -538,11 +588,9 @@ inline bool launch(const mfcc_k::StreamDesc &s, const Tables &t, float *out, int
     if (g.t_lo < 0) g.t_lo = 0;
     const long long hi = (s.n_samples - kSUsed) / kTileHop;
     g.t_hi = s.n_samples < kSUsed ? -1 : (int)(hi < tiles_per_ch ? hi : tiles_per_ch);
-    switch (t.sched) {
+    switch (t.variant) {
     case 1: hipLaunchKernelGGL(mfcc_fused1024_kernel<1>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out); break;
     case 2: hipLaunchKernelGGL(mfcc_fused1024_kernel<2>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out); break;
-    case 3: hipLaunchKernelGGL(mfcc_fused1024_kernel<3>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out); break;
-    case 4: hipLaunchKernelGGL(mfcc_fused1024_kernel<4>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out); break;
     default: hipLaunchKernelGGL(mfcc_fused1024_kernel<0>, dim3((unsigned)grid), dim3(64 * kWaves), 0, stream, s, t, g, out); break;
     }
     return true;

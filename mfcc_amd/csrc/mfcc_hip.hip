@@ -18,8 +18,7 @@
 #include "kernels_generic.hpp"
 #include "kernel_fixed512.hpp"
 #include "kernel_fused1024.hpp"
-#include "kernel_fused1024_t8.hpp"
-#include "kernel_fused1024_pc.hpp"
+#include "kernel_fused1024_f32.hpp"
 #include "kernel_fused512.hpp"
 #include "kernel_fused512_w12.hpp"
 #include "tables.hpp"
@@ -119,8 +118,6 @@ struct mfcc_hip_handle {
     bool fused_dense = false;     // the fused kernel's banded MFMA list does not fit this sample rate: all pairs
     bool fused_w12 = false;       // the twelve-wave form of the fused 512 kernel runs (kernel_fused512_w12.hpp)
     bool fused1k_ok = false;      // the fused 1024/341/40 float kernel covers this handle's parameters
-    bool fused1k8_ok = false;     // ... in its eight-frame-tile form (kernel_fused1024_t8.hpp)
-    bool fused1kpc_ok = false;    // ... in its producer / consumer form (kernel_fused1024_pc.hpp): the one that runs
     bool fixed512_ok = false;     // the fused fixed-point kernel covers this handle's parameters
     // device tables (one arena)
     void *arena = nullptr;
@@ -128,9 +125,9 @@ struct mfcc_hip_handle {
     mfcc_k::FixedTables xt{};
     mfcc_fused::FusedTables fu{};
     mfcc_fixed512::Tables x5{};
-    mfcc_fused1024::Tables f1k{};
-    mfcc_f1k::Tables f1k8{};
-    mfcc_f1kpc::Tables f1kpc{};
+    mfcc_fused1024::Tables f1k{};          // bf16-split contraction, set lists for every rate (kernel_fused1024.hpp)
+    mfcc_fused1024_f32::Tables f1k_f32{};  // fp32 contraction, one MFMA list per rate (kernel_fused1024_f32.hpp)
+    bool f1k_is_f32 = false;      // which of the two forms this handle's rate runs on
     // descriptor tables of the ragged calls live in pinned host memory, two buffers used in turn: the H2D copy of
     // an asynchronous call reads buffer i while the next call fills buffer 1 - i; the call after that waits for the
     // event recorded behind buffer i's copy before it overwrites it
@@ -323,26 +320,19 @@ int build_tables(mfcc_hip_handle *h) {
     size_t o_fu = 0;
     if (h->fused_ok) o_fu = a.put(fused_blob);
     std::vector<char> f1k_blob;
-    int f1k_sched = 0;
-    h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
-                    mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_sched);
+    int f1k_var = 0;
+    h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep);
+    if (h->fused1k_ok) {
+        // the fp32 form where it has a list for the rate (3 % faster there), the bf16 form everywhere else;
+        // MFCC_HIP_FUSED1024=bf16 / f32: diagnostic override for A/B runs
+        const char *e = std::getenv("MFCC_HIP_FUSED1024");
+        const bool no_f32 = e && !std::strcmp(e, "bf16"), no_bf16 = e && !std::strcmp(e, "f32");
+        h->f1k_is_f32 = !no_f32 && mfcc_fused1024_f32::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
+        if (!h->f1k_is_f32)
+            h->fused1k_ok = !no_bf16 && mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
+    }
     size_t o_f1k = 0;
     if (h->fused1k_ok) o_f1k = a.put(f1k_blob);
-    std::vector<char> f1k8_blob, f1kpc_blob;
-    int f1k8_var = 0, f1kpc_var = 0;
-    {
-        // diagnostic override for A/B runs: MFCC_HIP_FUSED1024=t16 keeps round 2's sixteen-frame-tile kernel, =t8 the
-        // eight-frame-tile one; the default is the producer / consumer form
-        const char *e = std::getenv("MFCC_HIP_FUSED1024");
-        const bool want_t16 = e && std::strcmp(e, "t16") == 0, want_t8 = e && std::strcmp(e, "t8") == 0;
-        h->fused1k8_ok = want_t8 && mfcc_f1k::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
-                         mfcc_f1k::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k8_blob, f1k8_var);
-        h->fused1kpc_ok = !want_t16 && !want_t8 && mfcc_f1k::supported(r.nfft, r.hop, r.n_mel, r.n_cep) &&
-                          mfcc_f1kpc::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1kpc_blob, f1kpc_var);
-    }
-    size_t o_f1k8 = 0, o_f1kpc = 0;
-    if (h->fused1k8_ok) o_f1k8 = a.put(f1k8_blob);
-    if (h->fused1kpc_ok) o_f1kpc = a.put(f1kpc_blob);
 
     HIP_TRY(h, hipMalloc(&h->arena, a.host.size() + 256));
     HIP_TRY(h, hipMemcpy(h->arena, a.host.data(), a.host.size(), hipMemcpyHostToDevice));
@@ -382,9 +372,10 @@ int build_tables(mfcc_hip_handle *h) {
         const char *e = std::getenv("MFCC_HIP_FUSED512");
         h->fused_w12 = h->fused_ok && !(e && std::strcmp(e, "w4") == 0);
     }
-    if (h->fused1k_ok) mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, f1k_sched, h->f1k);
-    if (h->fused1k8_ok) mfcc_f1k::bind_tables(b + o_f1k8, r.n_cep, f1k8_var, h->f1k8);
-    if (h->fused1kpc_ok) mfcc_f1kpc::bind_tables(b + o_f1kpc, r.n_cep, f1kpc_var, h->f1kpc);
+    if (h->fused1k_ok) {
+        if (h->f1k_is_f32) mfcc_fused1024_f32::bind_tables(b + o_f1k, r.n_cep, f1k_var, h->f1k_f32);
+        else mfcc_fused1024::bind_tables(b + o_f1k, r.n_cep, f1k_var, h->f1k);
+    }
     if (h->fixed512_ok) {
         mfcc_fixed512::bind_tables(b + o_x5, h->x5);
         h->x5.tw64a = x5_tw[0]; h->x5.tw64b = x5_tw[1]; h->x5.tw192a = x5_tw[2]; h->x5.tw192b = x5_tw[3];
@@ -459,14 +450,9 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
                           mfcc_fused12::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream);
         if (!done && !mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
-    } else if (h->fused1kpc_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
-               mfcc_f1kpc::launch(s, h->f1kpc, static_cast<float *>(d_out), h->n_cu, h->stream)) {
-        // fused 1024/341/40 kernel launched (producer / consumer form)
-    } else if (h->fused1k8_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
-               mfcc_f1k::launch(s, h->f1k8, static_cast<float *>(d_out), h->n_cu, h->stream)) {
-        // fused 1024/341/40 kernel launched (eight-frame tiles)
-    } else if (h->fused1k_ok && !h->fused1k8_ok && !h->fused1kpc_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
-               mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) {
+    } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
+               (h->f1k_is_f32 ? mfcc_fused1024_f32::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream)
+                              : mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream))) {
         // fused 1024/341/40 kernel launched
     } else {
         long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
@@ -1102,8 +1088,6 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return h->fused_w12 ? mfcc_fused12::kernel_name() : mfcc_fused::kernel_name();
-    if (h->fused1kpc_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_f1kpc::kernel_name();
-    if (h->fused1k8_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_f1k::kernel_name();
     if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_fused1024::kernel_name();
     return "mfcc_float_generic_kernel";
 }
@@ -1446,26 +1430,6 @@ int mfcc_hip_debug_read_stamps12(unsigned long long *dst) {
         return MFCC_HIP_ERROR_OTHER;
     unsigned long long z[48] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_fused12::g_stamps12), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
-    return MFCC_HIP_SUCCESS;
-}
-#endif
-
-#ifdef MFCC_F1KPC_STAMPS
-int mfcc_hip_debug_read_stampspc(unsigned long long *dst) {
-    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_f1kpc::g_stampspc), sizeof(unsigned long long) * 40) != hipSuccess)
-        return MFCC_HIP_ERROR_OTHER;
-    unsigned long long z[40] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_f1kpc::g_stampspc), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
-    return MFCC_HIP_SUCCESS;
-}
-#endif
-
-#ifdef MFCC_F1K_STAMPS
-int mfcc_hip_debug_read_stamps1k(unsigned long long *dst) {
-    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_f1k::g_stamps1k), sizeof(unsigned long long) * 52) != hipSuccess)
-        return MFCC_HIP_ERROR_OTHER;
-    unsigned long long z[52] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_f1k::g_stamps1k), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
     return MFCC_HIP_SUCCESS;
 }
 #endif
