@@ -61,11 +61,12 @@ constexpr int kNfft = 512, kHop = 170, kMel = 32, kMaxCep = 32;   // 32 = all of
 constexpr int kTile = 16;                 // frames per workgroup tile (MFMA N dimension)
 constexpr int kWaves = 4;
 constexpr int kTileHop = kTile * kHop;    // 2720 samples between consecutive tiles
-constexpr int kTRow = 34;                 // words per n2 row of the transpose tile
-constexpr int kTFrame = 16 * kTRow + 2;   // 546 words per frame (== 2 mod 32): pass 2 reads one column of 16
-                                          // frames per 16 lanes with ds_read2_b64 (32-bank addressing, 16 lanes
-                                          // per access) -- 16 distinct 8-byte bank pairs; 548 cost a 2-way
-                                          // conflict on every one of them (SQ_LDS_BANK_CONFLICT)
+constexpr int kTRow = 36;                 // words per k1 row of the transpose tile T[frame][k1][n2]: 16 complex + 4
+constexpr int kTFrame = 16 * kTRow + 8;   // 584 words per frame.  Pass 1 stores T[frame][k1][n2] with the lanes of a store on
+                                          // consecutive n2; pass 2 reads a column's 16 values -- contiguous -- with 8
+                                          // ds_read_b128 (256 B/clk; rounds 1-2: T[frame][n2][k1], 8 ds_read2_b64 at 128).
+                                          // (row, frame) strides of (9, 146) 16-byte units: conflict free (brute-forced
+                                          // over the ds_read_b128 lane groups)
 constexpr int kVStride = 18;              // words per frame in the column-16 tile
 constexpr int kAmelBanded = 17;           // mel A operands per wave at 16 kHz: block 0 k2 = 0,1,14,15; block 1 k2 = 2..14
 constexpr int kAmelDense = 32;            // any other band structure: every (k2, block) pair
@@ -746,9 +747,9 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         MFCC_STAMP(7);
 
         // transpose through LDS: T[frame][n2][k1]
-        mfcc_codelets::v2f *trow = reinterpret_cast<mfcc_codelets::v2f *>(Tt + fr_id * kTFrame + lo * kTRow);
+        mfcc_codelets::v2f *tcol0 = reinterpret_cast<mfcc_codelets::v2f *>(Tt + fr_id * kTFrame) + lo;
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
+        for (int k1 = 0; k1 < 16; ++k1) tcol0[k1 * (kTRow / 2)] = ty[k1];
         Vt[fr_id * kVStride + lo] = y16;
         MFCC_STAMP(0);
         lds_barrier();                         // B1: T and V of all 16 frames are in LDS; S and Q are consumed
@@ -758,10 +759,13 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         float pw[16];                            // |X|^2 at bin(wave, q, k2)
         {
             mfcc_codelets::v2f x[16], z[16];
-            const mfcc_codelets::v2f *tcol =
-                reinterpret_cast<const mfcc_codelets::v2f *>(Tt + lo * kTFrame + 2 * (4 * wave + q));
+            const f32x4 *trow = reinterpret_cast<const f32x4 *>(Tt + lo * kTFrame + (4 * wave + q) * kTRow);
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 a = trow[i];
+                x[2 * i] = (mfcc_codelets::v2f){a[0], a[1]};
+                x[2 * i + 1] = (mfcc_codelets::v2f){a[2], a[3]};
+            }
             MFCC_STAMP(1);
             mfcc_codelets::cfft16(x, z);
 #pragma unroll

@@ -334,9 +334,9 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             v2f ty[16];
             float y16;
             mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
-            v2f *trow = reinterpret_cast<v2f *>(T + fr_id * kTFrame + lo * kTRow);
+            v2f *tcol0 = reinterpret_cast<v2f *>(T + fr_id * kTFrame) + lo;        // a store's lanes: consecutive n2
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) trow[k1] = ty[k1];
+            for (int k1 = 0; k1 < 16; ++k1) tcol0[k1 * (kTRow / 2)] = ty[k1];
             V[fr_id * kVStride + lo] = y16;
         };
         auto pass2 = [&]() {
@@ -345,9 +345,13 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             float pw[16];
             {
                 v2f x[16], z[16];
-                const v2f *tcol = reinterpret_cast<const v2f *>(T + lo * kTFrame + 2 * (4 * wi + q));
+                const f32x4 *trow = reinterpret_cast<const f32x4 *>(T + lo * kTFrame + (4 * wi + q) * kTRow);
 #pragma unroll
-                for (int n2 = 0; n2 < 16; ++n2) x[n2] = tcol[n2 * (kTRow / 2)];
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 a = trow[i];
+                    x[2 * i] = (v2f){a[0], a[1]};
+                    x[2 * i + 1] = (v2f){a[2], a[3]};
+                }
                 mfcc_codelets::cfft16(x, z);
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
