@@ -434,7 +434,9 @@ def bench_batch(cx, args, cid, steps, warmup, pcm=None, with_cpu=False, headline
             f(hp)
         tp = (time.perf_counter() - t1) / 3
         pcie = {"value": round(8 * frames_per_ch / tp, 1), "unit": "frames/s",
-                "what": "mfcc_hip_process_i16 on host buffers, 8 channels: H2D + kernel + D2H, chunks overlapped"}
+                "input_gbs": round(hp.nbytes / tp / 1e9, 1),
+                "what": "mfcc_hip_process_i16 on pageable host buffers, 8 channels (154 MB): 64-MB chunks pinned in place, "
+                        "H2D / kernel / D2H of neighbouring chunks overlapped"}
 
     line = None
     if rank == 0:

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -176,24 +177,83 @@ inline bool build_mel_lanes(const std::vector<int> &start, const std::vector<int
         if (need <= 64) break;
     }
     if (chunk > kMelChunk) return false;
-    lanes.assign(64 * 4, 0);
-    wl.assign(size_t(kMelChunk) * 64, 0u);
     span = 0;
-    int l = 0;
     for (int f = 0; f < nf; ++f) {
         const int k = count[f] > 0 ? (count[f] + chunk - 1) / chunk : 1;
         if (k - 1 > span) span = k - 1;
-        for (int i = 0; i < k; ++i, ++l) {
+    }
+    if (span > kMelSpanMax) return false;
+    // Which lane takes which piece, and where its reads begin.  Lane l reads the power values X[first_l + u], u = 0 ..
+    // taps - 1 (taps = chunk rounded up to even: the kernel's loop runs in pairs), one ds_read_b32 per u over all 64 lanes,
+    // i.e. two groups of 32 lanes with 32 banks each: the cost of every one of those reads is the largest number of
+    // DIFFERENT addresses on one bank, which only depends on the residues first_l mod 32 inside each half of the wave.
+    // With the pieces in filter order that was 3 + 3 LDS cycles per read where 1 + 1 is free of conflicts (round 2's
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 19 % came from here).  Two freedoms cost nothing: the ORDER of the
+    // filters over the lanes (a filter's pieces must stay in consecutive lanes for the segmented reduction, nothing else),
+    // and a piece shorter than `taps` may BEGIN up to taps - len bins early against zero weights.  A few thousand random
+    // orders with greedy shifts find 1 + 2 or better for every rate tried; the search is deterministic (fixed seed).
+    const int taps = (chunk + 1) & ~1;
+    struct Piece { int first, len, filt, head, last_lane_rel; };
+    std::vector<std::vector<Piece>> P(nf);
+    for (int f = 0; f < nf; ++f) {
+        const int k = count[f] > 0 ? (count[f] + chunk - 1) / chunk : 1;
+        for (int i = 0; i < k; ++i) {
             int n = count[f] - i * chunk;
             n = n < 0 ? 0 : (n > chunk ? chunk : n);
-            lanes[l * 4 + 0] = start[f] + i * chunk;
-            lanes[l * 4 + 2] = f | ((i == 0) << 8);
-            lanes[l * 4 + 3] = l - i + k - 1;
-            for (int u = 0; u < n; ++u) wl[size_t(u) * 64 + l] = w[off[f] + i * chunk + u];
+            P[f].push_back({start[f] + i * chunk, n, f, i == 0, k - 1 - i});
         }
     }
+    std::vector<int> order(nf), best_order, best_first;
+    for (int f = 0; f < nf; ++f) order[f] = f;
+    int best_cost = 1 << 30;
+    uint32_t rng = 12345u;
+    auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (int iter = 0; iter < 4000 && best_cost > 2; ++iter) {
+        if (iter) for (int i = nf - 1; i > 0; --i) std::swap(order[i], order[next() % (uint32_t)(i + 1)]);
+        std::vector<int> first;
+        std::vector<int> addr[2][32];                 // distinct addresses per (half, bank)
+        int l = 0;
+        for (int oi = 0; oi < nf; ++oi)
+            for (const Piece &p : P[order[oi]]) {
+                const int half = l < 32 ? 0 : 1;
+                int pick = p.first, pick_mult = 1 << 30;
+                for (int d = 0; d <= taps - p.len && p.first - d >= 0; ++d) {
+                    const int a = p.first - d;
+                    int mult = 0;
+                    bool same = false;
+                    for (int o : addr[half][a & 31]) { if (o == a) same = true; else ++mult; }
+                    (void)same;                       // an address another lane already reads is a broadcast: free
+                    if (mult < pick_mult) { pick_mult = mult; pick = a; }
+                    if (mult == 0) break;
+                }
+                bool have = false;
+                for (int o : addr[half][pick & 31]) have = have || o == pick;
+                if (!have) addr[half][pick & 31].push_back(pick);
+                first.push_back(pick);
+                ++l;
+            }
+        int cost = 0;
+        for (int half = 0; half < 2; ++half) {
+            size_t m = 1;
+            for (int b = 0; b < 32; ++b) m = std::max(m, addr[half][b].size());
+            cost += (int)m;
+        }
+        if (cost < best_cost) { best_cost = cost; best_order = order; best_first = first; }
+    }
+    lanes.assign(64 * 4, 0);
+    wl.assign(size_t(kMelChunk) * 64, 0u);
+    int l = 0;
+    for (int oi = 0; oi < nf; ++oi)
+        for (const Piece &p : P[best_order[oi]]) {
+            const int d = p.first - best_first[l];         // bins the lane reads before its piece: weight 0
+            lanes[l * 4 + 0] = best_first[l];
+            lanes[l * 4 + 2] = p.filt | (p.head << 8);
+            lanes[l * 4 + 3] = l + p.last_lane_rel;
+            for (int u = 0; u < p.len; ++u) wl[size_t(d + u) * 64 + l] = w[off[p.filt] + (p.first - start[p.filt]) + u];
+            ++l;
+        }
     for (; l < 64; ++l) lanes[l * 4 + 3] = l;         // spare lanes: no bins, no filter, a segment of their own
-    return span <= kMelSpanMax;
+    return true;
 }
 
 inline void bind_tables(const char *b, Tables &t) {

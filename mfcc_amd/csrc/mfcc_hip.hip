@@ -6,6 +6,7 @@
 // strings -- keep working so the CPU test-suite can check the host logic).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -143,13 +144,17 @@ struct mfcc_hip_handle {
     // waits for it on the device (an event outlives the stream it was recorded on)
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
-    void *d_hin = nullptr, *d_hout = nullptr;      // host-buffer ragged calls: the corpus and its rows on the device
-    size_t d_hin_bytes = 0, d_hout_bytes = 0;
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
     hipEvent_t scratch_done = nullptr;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
+    // host-buffer pipeline (process_host): copy streams of their own, three chunks in flight
+    static constexpr int kPipe = 3;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[kPipe] = {}, ev_k[kPipe] = {}, ev_out[kPipe] = {};
+    void *p_in[kPipe] = {}, *p_out[kPipe] = {};
+    size_t p_in_bytes[kPipe] = {}, p_out_bytes[kPipe] = {};
     // streaming sessions opened on this handle that are still alive.  mfcc_hip_destroy with live sessions only marks
     // the handle; the last mfcc_hip_stream_destroy then tears it down (include/mfcc_hip.h: lifetime)
     int n_sessions = 0;
@@ -501,6 +506,196 @@ int ensure(mfcc_hip_handle *h, void **p, size_t *have, size_t want) {
     return MFCC_HIP_SUCCESS;
 }
 
+// ---- host buffers in, host buffers out: the shape of the reference's own caller (software/main.c:100-177: file in,
+// file out).  The input crosses PCIe at 340 B per frame, which is 25 times what the kernel needs per frame in time, so this
+// path is a COPY pipeline: the batch is cut into chunks of ~64 MB (whole channels, or frame ranges of a long channel with
+// a one-sample history halo), three chunks in flight -- H2D of chunk k + 1 on one copy stream, the kernel of chunk k on
+// the handle's stream, D2H of chunk k - 1 on another.  An asynchronous copy from pageable memory blocks the calling thread
+// until it is done (measured: hipMemcpyAsync of 154 MB returned after 8.6 ms); pinned in place with hipHostRegister (13 us
+// per MB, done for chunk k + 1 while chunk k is on the wire) it returns in 20 us.  Round 2 ran copy, kernel, copy in series.
+// Measured on 8 channels x 10 min (154 MB in, 23 MB out; tools/hostio_sweep.sh, median of 15): one chunk unpinned 3.42 ms,
+// 64 MB chunks pinned 3.20 ms (0.141 G frames/s = 48 GB/s of input against 53 GB/s for the bare H2D copy), 32 MB 3.68,
+// 16 MB 3.94 -- every chunk costs ~60 us of calls and a kernel launch that cannot fill the chip.  A batch that fits one
+// chunk takes the plain blocking copies (pinning it first only adds its 13 us per MB in front).
+struct HostChunk {
+    const int16_t *in;      // first sample handed to the kernel (the halo sample when halo = 1)
+    size_t in_samples;      // samples copied (all channels of the chunk; incl. the halo sample)
+    size_t n, stride, nch;  // launch geometry: samples per channel after the halo, channel stride, channels
+    int halo;
+    size_t frames;          // frames per channel of this chunk (forced: a frame range of a longer stream)
+    size_t out_elems;       // coefficients written
+    size_t out_off;         // offset into `out`, in elements
+};
+
+// A caller's buffer pinned block by block for the duration of a call: page-aligned blocks of 16 MB, registered when a
+// copy first touches them and released when every chunk that could touch them is done.  A copy must stay inside ONE
+// registration (the runtime resolves a host pointer to the allocation it lies in and rejects a size that runs past it),
+// so copies are split at block boundaries.
+struct PinnedSpan {
+    static constexpr size_t kBlock = size_t(16) << 20;
+    char *base = nullptr;
+    size_t nblocks = 0, total = 0;
+    std::vector<char> state;      // 0: untouched, 1: pinned by us, 2: tried, not ours (already pinned or not pinnable)
+    void init(const void *p, size_t bytes) {
+        const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
+        const uintptr_t b = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+        base = reinterpret_cast<char *>(a);
+        total = size_t(b - a);
+        nblocks = (total + kBlock - 1) / kBlock;
+        state.assign(nblocks, 0);
+    }
+    size_t block_bytes(size_t k) const { return std::min(kBlock, total - k * kBlock); }
+    void ensure(const void *p, size_t bytes) {
+        if (!bytes) return;
+        const size_t k0 = size_t(static_cast<const char *>(p) - base) / kBlock;
+        const size_t k1 = size_t(static_cast<const char *>(p) + bytes - 1 - base) / kBlock;
+        for (size_t k = k0; k <= k1 && k < nblocks; ++k)
+            if (!state[k]) {
+                state[k] = hipHostRegister(base + k * kBlock, block_bytes(k), hipHostRegisterDefault) == hipSuccess ? 1 : 2;
+                if (state[k] == 2) (void)hipGetLastError();
+            }
+    }
+    // blocks that end at or below p are no longer needed
+    void release_below(const void *p) {
+        for (size_t k = 0; k < nblocks && base + k * kBlock + block_bytes(k) <= static_cast<const char *>(p); ++k)
+            if (state[k] == 1) {
+                (void)hipHostUnregister(base + k * kBlock);
+                state[k] = 2;
+            }
+    }
+    void release_all() {
+        for (size_t k = 0; k < nblocks; ++k)
+            if (state[k] == 1) {
+                (void)hipHostUnregister(base + k * kBlock);
+                state[k] = 2;
+            }
+    }
+    // hipMemcpyAsync in pieces that do not cross a block boundary
+    hipError_t copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) const {
+        const char *host = static_cast<const char *>(kind == hipMemcpyHostToDevice ? src : dst);
+        size_t done = 0;
+        while (done < bytes) {
+            const size_t k = size_t(host + done - base) / kBlock;
+            const size_t room = size_t(base + k * kBlock + block_bytes(k) - (host + done));
+            const size_t len = std::min(bytes - done, room);
+            const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + done, static_cast<const char *>(src) + done, len, kind, st);
+            if (e != hipSuccess) return e;
+            done += len;
+        }
+        return hipSuccess;
+    }
+};
+
+// one chunk of a host-buffer call as the pipeline sees it: bytes in, bytes out
+struct PipeChunk {
+    const void *in;
+    size_t in_bytes;
+    void *out;
+    size_t out_bytes;
+};
+
+// the pipeline itself: H2D of chunk i + 1 | enqueue(i, d_in, d_out) on the handle's stream | D2H of chunk i - 1.  The
+// chunks must ascend in both host buffers ([in_lo, in_lo + in_total) and [out_lo, out_lo + out_total) are what gets pinned).
+template <typename Enqueue>
+int run_host_pipeline(mfcc_hip_handle *h, const std::vector<PipeChunk> &chunks, const void *in_lo, size_t in_total,
+                      void *out_lo, size_t out_total, Enqueue &&enqueue) {
+    constexpr int kPipe = mfcc_hip_handle::kPipe;
+    const size_t nchunks = chunks.size();
+    if (!nchunks) return MFCC_HIP_SUCCESS;
+    bool no_pin = false;
+    if (const char *e = std::getenv("MFCC_HIP_HOST_NOPIN")) no_pin = e[0] == '1';                  // diagnostic
+    if (!h->s_in) HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    if (!h->s_out) HIP_TRY(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    size_t max_in = 0, max_out = 0;
+    for (const PipeChunk &c : chunks) {
+        max_in = std::max(max_in, c.in_bytes);
+        max_out = std::max(max_out, c.out_bytes);
+    }
+    const int nbuf = int(std::min<size_t>(kPipe, nchunks));
+    for (int i = 0; i < nbuf; ++i) {
+        if (!h->ev_in[i]) {
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming));
+        }
+        int rc = ensure(h, &h->p_in[i], &h->p_in_bytes[i], max_in + 64);
+        if (rc) return rc;
+        if ((rc = ensure(h, &h->p_out[i], &h->p_out_bytes[i], max_out + 64))) return rc;
+    }
+    // the copy streams start behind whatever is queued on the handle's stream
+    HIP_TRY(h, hipEventRecord(h->ev_k[0], h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_in, h->ev_k[0], 0));
+
+    // a batch that fits one chunk takes the plain blocking copies: pinning it first only adds its cost in front
+    const bool pin_it = !no_pin && nchunks > 1;
+    PinnedSpan pin_in, pin_out;
+    pin_in.init(in_lo, in_total);
+    pin_out.init(out_lo, out_total);
+    if (!pin_it) {
+        pin_in.state.assign(pin_in.nblocks, 2);
+        pin_out.state.assign(pin_out.nblocks, 2);
+    }
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(h->s_in);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->s_out);
+        pin_in.release_all();
+        pin_out.release_all();
+        return code;
+    };
+    // what lies below the next unfinished chunk is released as the pipeline moves on, what lies ahead is pinned one chunk
+    // early (on the CPU, while the wire is busy)
+    auto pin = [&](size_t i) {
+        pin_in.ensure(chunks[i].in, chunks[i].in_bytes);
+        pin_out.ensure(chunks[i].out, chunks[i].out_bytes);
+    };
+    pin(0);
+#define PIPE_TRY(expr)                                   \
+    do {                                                 \
+        const hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) {                         \
+            h->last_hip = int(e__);                      \
+            return fail(MFCC_HIP_ERROR_OTHER);           \
+        }                                                \
+    } while (0)
+    for (size_t i = 0; i < nchunks; ++i) {
+        const PipeChunk &c = chunks[i];
+        const int slot = int(i % kPipe);
+        if (i + 1 < nchunks) pin(i + 1);
+        if (i >= size_t(kPipe)) {
+            // slot reuse: chunk i - kPipe's kernel has read p_in[slot] / its rows have left p_out[slot]
+            PIPE_TRY(hipStreamWaitEvent(h->s_in, h->ev_k[slot], 0));
+            PIPE_TRY(hipStreamWaitEvent(h->stream, h->ev_out[slot], 0));
+            PIPE_TRY(hipEventSynchronize(h->ev_out[slot]));
+            // chunks 0 .. i - kPipe are done (copies, kernel, rows): nothing touches what lies below the next one
+            pin_in.release_below(chunks[i - kPipe + 1].in);
+            pin_out.release_below(chunks[i - kPipe + 1].out);
+        }
+        if (c.in_bytes) PIPE_TRY(pin_in.copy(h->p_in[slot], c.in, c.in_bytes, hipMemcpyHostToDevice, h->s_in));
+        PIPE_TRY(hipEventRecord(h->ev_in[slot], h->s_in));
+        PIPE_TRY(hipStreamWaitEvent(h->stream, h->ev_in[slot], 0));
+        const int rc = enqueue(i, h->p_in[slot], h->p_out[slot]);
+        if (rc) return fail(rc);
+        PIPE_TRY(hipEventRecord(h->ev_k[slot], h->stream));
+        PIPE_TRY(hipStreamWaitEvent(h->s_out, h->ev_k[slot], 0));
+        if (c.out_bytes) PIPE_TRY(pin_out.copy(c.out, h->p_out[slot], c.out_bytes, hipMemcpyDeviceToHost, h->s_out));
+        PIPE_TRY(hipEventRecord(h->ev_out[slot], h->s_out));
+    }
+    PIPE_TRY(hipStreamSynchronize(h->s_out));
+#undef PIPE_TRY
+    // the handle's stream continues behind the last rows
+    (void)hipStreamWaitEvent(h->stream, h->ev_out[int((nchunks - 1) % kPipe)], 0);
+    pin_in.release_all();
+    pin_out.release_all();
+    return MFCC_HIP_SUCCESS;
+}
+
+inline size_t host_chunk_bytes() {
+    size_t b = size_t(64) << 20;
+    if (const char *e = std::getenv("MFCC_HIP_HOST_CHUNK_MB")) b = size_t(std::atoi(e) > 0 ? std::atoi(e) : 64) << 20;   // diagnostic
+    return b;
+}
+
 template <typename OutT>
 int process_host(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, size_t n, size_t nch, OutT *out,
                  size_t cap, size_t *n_frames) {
@@ -509,22 +704,44 @@ int process_host(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, size_t n, s
     const size_t nf = count_frames(h->r, n);
     if (n_frames) *n_frames = nf;
     if (nf == 0 || nch == 0) return MFCC_HIP_SUCCESS;
-    const size_t n_out = nf * nch * size_t(h->r.n_cep);
+    const size_t ncep = size_t(h->r.n_cep), hop = size_t(h->r.hop), nfft = size_t(h->r.nfft);
+    const size_t n_out = nf * nch * ncep;
     if (!out || cap < n_out) return MFCC_HIP_ERROR_BUFFER_SMALL;
     DeviceGuard guard(h->device);
-    const size_t in_bytes = n * nch * sizeof(int16_t);
-    int rc = ensure(h, &h->d_in, &h->d_in_bytes, in_bytes + 64);
-    if (rc) return rc;
-    rc = ensure(h, &h->d_out, &h->d_out_bytes, n_out * sizeof(OutT));
-    if (rc) return rc;
-    if ((rc = scratch_acquire(h))) return rc;
-    if (in_bytes) HIP_TRY(h, hipMemcpyAsync(h->d_in, pcm, in_bytes, hipMemcpyHostToDevice, h->stream));
-    rc = launch(h, fixed, h->d_in, n, n, nch, 0, h->d_out, nullptr);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out, h->d_out, n_out * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
-    if ((rc = scratch_release(h))) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return MFCC_HIP_SUCCESS;
+    const size_t kChunkBytes = host_chunk_bytes();
+
+    // ---- the chunks
+    std::vector<HostChunk> chunks;
+    const size_t ch_bytes = n * sizeof(int16_t);
+    if (ch_bytes <= kChunkBytes) {
+        size_t per = kChunkBytes / (ch_bytes ? ch_bytes : 1);
+        if (per < 1) per = 1;
+        for (size_t c0 = 0; c0 < nch; c0 += per) {
+            const size_t k = std::min(per, nch - c0);
+            chunks.push_back({pcm + c0 * n, k * n, n, n, k, 0, nf, k * nf * ncep, c0 * nf * ncep});
+        }
+    } else {
+        // long channels: frame ranges [f0, f1) of one channel -- samples f0 * hop - 1 (history) .. (f1 - 1) * hop + nfft
+        size_t per = (kChunkBytes / sizeof(int16_t)) / hop;
+        if (per < 1) per = 1;
+        for (size_t c = 0; c < nch; ++c)
+            for (size_t f0 = 0; f0 < nf; f0 += per) {
+                const size_t f1 = std::min(nf, f0 + per), halo = f0 ? 1 : 0;
+                const size_t s0 = f0 * hop - halo;
+                size_t s1 = (f1 - 1) * hop + nfft;
+                if (s1 > n) s1 = n;                                  // the zero-padded tail of STREAM framing
+                chunks.push_back({pcm + c * n + s0, s1 - s0, s1 - s0 - halo, s1 - s0, 1, int(halo), f1 - f0,
+                                  (f1 - f0) * ncep, (c * nf + f0) * ncep});
+            }
+    }
+    std::vector<PipeChunk> pc;
+    pc.reserve(chunks.size());
+    for (const HostChunk &c : chunks)
+        pc.push_back({c.in, c.in_samples * sizeof(int16_t), out + c.out_off, c.out_elems * sizeof(OutT)});
+    return run_host_pipeline(h, pc, pcm, nch * ch_bytes, out, n_out * sizeof(OutT), [&](size_t i, void *d_in, void *d_out) {
+        const HostChunk &c = chunks[i];
+        return launch(h, fixed, d_in, c.n, c.stride, c.nch, c.halo, d_out, nullptr, c.halo || c.frames != nf ? c.frames : 0);
+    });
 }
 
 // ---- ragged batch: many utterances of different lengths, one launch.
@@ -757,18 +974,40 @@ int process_ragged(mfcc_hip_handle *h, bool fixed, const int16_t *pcm, const siz
         return MFCC_HIP_ERROR_BUFFER_SMALL;
     }
     DeviceGuard guard(h->device);
-    const size_t span = rel[n_utt];
-    int rc = ensure(h, &h->d_hin, &h->d_hin_bytes, span * sizeof(int16_t) + 64);
-    if (rc) return rc;
-    rc = ensure(h, &h->d_hout, &h->d_hout_bytes, total * ncep * sizeof(OutT) + 64);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_hin, pcm + offsets[0], span * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
-    rc = process_ragged_dev<OutT>(h, fixed, static_cast<const int16_t *>(h->d_hin), rel.data(), n_utt,
-                                  static_cast<OutT *>(h->d_hout), total * ncep, frame_offsets);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out, h->d_hout, total * ncep * sizeof(OutT), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return MFCC_HIP_SUCCESS;
+    // the same copy pipeline as process_host: chunks of whole utterances, ~64 MB each; every chunk is one call of the
+    // device-resident ragged path on its own offsets, its rows land behind those of the chunk before it
+    const size_t kChunkBytes = host_chunk_bytes();
+    struct Range { size_t u0, u1, rows0; };
+    std::vector<Range> ranges;
+    std::vector<PipeChunk> pc;
+    {
+        size_t u0 = 0, rows = 0, rows0 = 0;
+        for (size_t u = 0; u < n_utt; ++u) {
+            rows += count_frames(h->r, rel[u + 1] - rel[u]);
+            const bool last = u + 1 == n_utt;
+            if (last || (rel[u + 1] - rel[u0]) * sizeof(int16_t) >= kChunkBytes) {
+                ranges.push_back({u0, u + 1, rows0});
+                pc.push_back({pcm + offsets[0] + rel[u0], (rel[u + 1] - rel[u0]) * sizeof(int16_t), out + rows0 * ncep,
+                              (rows - rows0) * ncep * sizeof(OutT)});
+                u0 = u + 1;
+                rows0 = rows;
+            }
+        }
+    }
+    frame_offsets[0] = 0;
+    std::vector<size_t> loc, fo;
+    return run_host_pipeline(h, pc, pcm + offsets[0], rel[n_utt] * sizeof(int16_t), out, total * ncep * sizeof(OutT),
+                             [&](size_t i, void *d_in, void *d_out) {
+        const Range &r = ranges[i];
+        const size_t k = r.u1 - r.u0;
+        loc.assign(k + 1, 0);
+        fo.assign(k + 1, 0);
+        for (size_t j = 0; j <= k; ++j) loc[j] = rel[r.u0 + j] - rel[r.u0];
+        const int rc = process_ragged_dev<OutT>(h, fixed, static_cast<const int16_t *>(d_in), loc.data(), k,
+                                                static_cast<OutT *>(d_out), pc[i].out_bytes / sizeof(OutT), fo.data());
+        for (size_t j = 1; j <= k; ++j) frame_offsets[r.u0 + j] = r.rows0 + fo[j];
+        return rc;
+    });
 }
 
 // ---- minimal RIFF/WAVE reader (the reference uses the un-vendored libwav, main.c:58-98)
@@ -986,10 +1225,17 @@ void mfcc_hip_destroy(mfcc_hip_handle *h) {
         }
         if (d.p) (void)hipHostFree(d.p);
     }
+    for (int i = 0; i < mfcc_hip_handle::kPipe; ++i) {
+        if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
+        if (h->ev_k[i]) (void)hipEventDestroy(h->ev_k[i]);
+        if (h->ev_out[i]) (void)hipEventDestroy(h->ev_out[i]);
+        if (h->p_in[i]) (void)hipFree(h->p_in[i]);
+        if (h->p_out[i]) (void)hipFree(h->p_out[i]);
+    }
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_in) (void)hipFree(h->d_in);
-    if (h->d_hin) (void)hipFree(h->d_hin);
-    if (h->d_hout) (void)hipFree(h->d_hout);
     if (h->d_out) (void)hipFree(h->d_out);
     delete h;
 }

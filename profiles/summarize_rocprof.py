@@ -54,13 +54,16 @@ def main(src, dst):
             continue
         fs.sort(key=os.path.getmtime)
         agg = collections.defaultdict(list)
+        per_dispatch = collections.defaultdict(float)      # a counter may come as one row per XCD / SE: sum them per dispatch
         meta = {}
         for r in csv.DictReader(open(fs[-1])):
             if "fused512" in r["Kernel_Name"] or "mfcc_float_generic" in r["Kernel_Name"] or \
-                    "mfcc_fixed" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    "mfcc_fixed" in r["Kernel_Name"] or "fused1024" in r["Kernel_Name"]:
+                per_dispatch[(r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
                 meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                            "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
+        for (name, _disp), v in per_dispatch.items():
+            agg[name].append(v)
         for k, v in agg.items():
             counters[k] = {"avg_per_launch": sum(v) / len(v), "launches": len(v), "pass": os.path.basename(d)}
         if meta:
@@ -82,6 +85,11 @@ def main(src, dst):
         if "SQ_INSTS_VALU" in counters:
             d["valu_wave_instructions_per_frame"] = counters["SQ_INSTS_VALU"]["avg_per_launch"] / frames
             d["valu_lane_ops_per_frame"] = 64.0 * counters["SQ_INSTS_VALU"]["avg_per_launch"] / frames
+        if "GRBM_GUI_ACTIVE" in counters and "kernel_trace" in out:
+            # MI355X_MICROARCH.md, DVFS give-back: effective clock = GRBM_GUI_ACTIVE / 8 / kernel wall time (rocprofv3 reports
+            # the sum over the 8 XCDs; reads high on dispatches shorter than ~0.3 ms).  The wall time is the kernel trace's
+            # average of the same bench command.
+            d["shader_clock_ghz"] = round(counters["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0 / out["kernel_trace"]["avg_ns"], 3)
         if "SQ_WAVE_CYCLES" in counters:
             wc = counters["SQ_WAVE_CYCLES"]["avg_per_launch"]
             for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"):

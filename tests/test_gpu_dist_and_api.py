@@ -175,3 +175,40 @@ def test_distinct_handles_on_distinct_host_threads_are_independent(mfcc_amd):
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors[:4]
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+@pytest.mark.parametrize("pad_mode", ["notebook", "stream"])
+def test_host_buffer_pipeline_chunks_equal_the_device_path(mfcc_amd, fixed, pad_mode, monkeypatch):
+    """`mfcc_hip_process_i16` on host buffers is a copy pipeline: chunks of whole channels, or frame ranges of a long
+    channel with a one-sample history halo, three in flight on two copy streams around the kernel, the caller's pages
+    pinned block by block.  Whatever the chunking, the rows are those of ONE launch over the same samples resident on
+    the device, bit for bit.  (Chunks are 64 MB by default; 4 MB here so that small inputs walk every path.)"""
+    import torch
+    monkeypatch.setenv("MFCC_HIP_HOST_CHUNK_MB", "4")
+    rng = np.random.default_rng(11)
+    shapes = [(1, 21_000_003),           # one long channel: frame-range chunks (41 MB -> 11 chunks), odd length
+              (5, 4_100_001),            # channels of 8.2 MB: frame ranges inside every channel
+              (7, 1_900_001),            # channels of 3.8 MB: one channel per chunk, more chunks than pipeline slots
+              (40, 300_007)]             # many short channels: several channels per chunk
+    with mfcc_amd.MFCC(nfft=512, nfilters=32, nceptrums=13, pad_mode=pad_mode) as m:
+        for nch, n in shapes:
+            x = (rng.standard_normal((nch, n)) * 3000).clip(-32768, 32767).astype(np.int16)
+            host = m.process_fixed(x) if fixed else m.process(x)
+            d = torch.from_numpy(x).cuda()
+            dev = (m.process_fixed(d) if fixed else m.process(d)).cpu().numpy()
+            assert host.shape == dev.shape == (nch, m.num_frames(n), 13)
+            assert np.array_equal(host, dev), (nch, n)
+            # a pinned caller buffer (already registered: the library must neither fail nor unpin it)
+            xp = torch.from_numpy(x).pin_memory()
+            again = m.process_fixed(xp.numpy()) if fixed else m.process(xp.numpy())
+            assert np.array_equal(again, dev)
+            del d, xp
+        # the ragged host path runs through the same pipeline in chunks of whole utterances
+        utts = [(rng.standard_normal(int(k)) * 3000).clip(-32768, 32767).astype(np.int16)
+                for k in rng.integers(0, 600_000, 50)]
+        many = m.process_batch(utts, fixed=fixed)
+        for i in (0, 7, 23, 49):
+            one = m.process_fixed(utts[i]) if fixed else m.process(utts[i])
+            assert np.array_equal(many[i], one, equal_nan=True), i
+        assert sum(len(r) for r in many) == sum(m.num_frames(len(u)) for u in utts)
