@@ -273,7 +273,7 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the packed butterfly (12 VALU ops) lives in kernels_generic.hpp: fx_combine / fx_rot14 / fx_bfly
+// the packed butterfly (9 VALU ops) lives in kernels_generic.hpp: fx_bfly (+ fx_combine / fx_rot14 for the odd forms)
 __device__ __forceinline__ void combine(uint32_t p0, int a1, int a2, uint32_t &o0, uint32_t &o1) {
     mfcc_k::fx_combine(p0, a1, a2, o0, o1);
 }
@@ -283,9 +283,7 @@ __device__ __forceinline__ void bfly(uint32_t &p0, uint32_t &p1, uint32_t twa, u
 }
 
 // twiddle T[0] = (16384, 0): (x * 16384 + 8191) >> 14 == x
-__device__ __forceinline__ void bfly_one(uint32_t &p0, uint32_t &p1) {
-    combine(p0, (int)(short)(p1 & 0xffffu), (int)p1 >> 16, p0, p1);
-}
+__device__ __forceinline__ void bfly_one(uint32_t &p0, uint32_t &p1) { mfcc_k::fx_bfly_one(p0, p1); }
 
 // twiddle T[size/4] = (0, -16384): a1 = x1i, a2 = (-16384 x1r + 8191) >> 14 == -x1r
 __device__ __forceinline__ void bfly_mi(uint32_t &p0, uint32_t &p1) {
@@ -302,7 +300,10 @@ __device__ __forceinline__ void round3(uint32_t (&x)[8], const uint32_t (&tw)[14
     for (int r = 0; r < 8; ++r)
         if (!(r & 2)) bfly(x[r], x[r + 2], tw[2 + 2 * (r & 1)], tw[3 + 2 * (r & 1)]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bfly(x[r], x[r + 4], tw[6 + 2 * r], tw[7 + 2 * r]);   // LAST: x[r+4] is not read out
+    for (int r = 0; r < 4; ++r) {
+        if constexpr (LAST) mfcc_k::fx_bfly_y0(x[r], x[r + 4], tw[6 + 2 * r], tw[7 + 2 * r]);   // x[r+4] is not read out
+        else bfly(x[r], x[r + 4], tw[6 + 2 * r], tw[7 + 2 * r]);
+    }
 }
 
 // stage ST >= 1 of the DCT's 64-point FFT on two values per lane: swap one value with the lane 2^(ST-1) away

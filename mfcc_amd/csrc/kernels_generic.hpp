@@ -274,8 +274,62 @@ __device__ __forceinline__ int fx_rot14(uint32_t p1, uint32_t tw) {
     return r >> 14;
 }
 
+// The whole butterfly in NINE vector instructions (round 2: twelve -- fx_rot14 x 2 + fx_combine).  With
+// s = dot2(x1, tw) + 8191 and b = s >> 14 (the rotated x1, floor), the RTL's outputs are y0 = wrap16((x0 + b) >> 1) and
+// y1 = wrap16((x0 - b) >> 1) per component (mfcc/misc/fft.py:140-192).  Two identities over the integers:
+//   (x0 + (s >> 14)) >> 1  ==  (x0 * 2^14 + s) >> 15          floor of a floor; |x0 2^14 + s| < 2^31, SURVEY.md A.4
+//   (x0 + b) >> 1  -  (x0 - b) >> 1  ==  b                     x0 + b and x0 - b have the same parity
+// so y0 is ONE v_mad_i32_i16 per component on top of the dot product (the multiply-add takes the 16-bit half of the
+// packed x0 it needs, sign-extended, by op_sel) plus the pack, and y1 = y0 - b is one PACKED 16-bit subtraction once b's
+// low halves are packed -- the wrap to 16 bits is the packed arithmetic itself.
 __device__ __forceinline__ void fx_bfly(uint32_t &p0, uint32_t &p1, uint32_t twa, uint32_t twb) {
-    fx_combine(p0, fx_rot14(p1, twa), fx_rot14(p1, twb), p0, p1);
+    const int bias = 8191, two14 = 16384, fifteen = 15, fourteen = 14;
+    int s1, s2, tr, ti;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s1) : "v"(p1), "v"(twa), "s"(bias));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s2) : "v"(p1), "v"(twb), "s"(bias));
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(tr) : "v"(p0), "s"(two14), "v"(s1));                    // x0r 2^14 + s1
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ti) : "v"(p0), "s"(two14), "v"(s2));   // x0i 2^14 + s2
+    uint32_t y0 = (uint32_t)tr >> 15, b = (uint32_t)s1 >> 14;            // the low halves; the high ones are written next
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(y0) : "s"(fifteen), "v"(ti));
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(b) : "s"(fourteen), "v"(s2));
+    uint32_t y1;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(y1) : "v"(y0), "v"(b));
+    p0 = y0;
+    p1 = y1;
+}
+
+// the same when only y0 is read out (the last stage of the frame FFT keeps bins 0..255): six instructions
+__device__ __forceinline__ void fx_bfly_y0(uint32_t &p0, uint32_t p1, uint32_t twa, uint32_t twb) {
+    const int bias = 8191, two14 = 16384, fifteen = 15;
+    int s1, s2, tr, ti;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s1) : "v"(p1), "v"(twa), "s"(bias));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s2) : "v"(p1), "v"(twb), "s"(bias));
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(tr) : "v"(p0), "s"(two14), "v"(s1));
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ti) : "v"(p0), "s"(two14), "v"(s2));
+    uint32_t y0 = (uint32_t)tr >> 15;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(y0) : "s"(fifteen), "v"(ti));
+    p0 = y0;
+}
+
+// twiddle T[0] = (16384, 0): the rotated x1 is x1 itself ((x 16384 + 8191) >> 14 == x), so b is the packed x1 as it is:
+// y0 = (x0 + x1) >> 1 per component in 17 bits (two SDWA adds, a shift, an SDWA shift), y1 = y0 - x1 packed.  Five.
+__device__ __forceinline__ void fx_bfly_one(uint32_t &p0, uint32_t &p1) {
+    const int one = 1;
+    int tr, ti;
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0"
+        : "=v"(tr) : "v"(p0), "v"(p1));
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
+        : "=v"(ti) : "v"(p0), "v"(p1));
+    uint32_t y0 = (uint32_t)tr >> 1;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(y0) : "s"(one), "v"(ti));
+    uint32_t y1;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(y1) : "v"(y0), "v"(p1));
+    p0 = y0;
+    p1 = y1;
 }
 
 // LDS index of point i of the in-place FFT buffer: one pad word per 32 points.  The butterfly groups of a stage
