@@ -463,7 +463,7 @@ def bench_batch(cx, args, cid, steps, warmup, pcm=None, with_cpu=False, headline
                 "bytes_per_frame": bpf,
                 "parallelism": "frames sharded by channel across %d GPU(s), no data-path collective" % world,
                 "kernel": kname,
-                "fallback": "generic" in kname or kname == "mfcc_fixed_kernel",      # a generic kernel runs: 3-6 x slower
+                "fallback": m.is_fallback(fixed=fixed),      # a generic kernel runs: 3-6 x slower
                 "prewarm_s": PREWARM_S,
             },
             "roofline": roof,
@@ -588,7 +588,7 @@ def bench_config5(cx, args, steps, warmup, with_cpu):
                 "bytes_per_frame": bpf,
                 "parallelism": "utterances %d..%d on rank 0 (plan_items), no data-path collective" % (mine.start, mine.stop - 1),
                 "kernel": kname,
-                "fallback": "generic" in kname or kname == "mfcc_fixed_kernel",
+                "fallback": m.is_fallback(fixed=fixed),
             },
             "roofline": roof,
             "host_enqueue": enq,
@@ -633,7 +633,7 @@ def main():
             del pcm
             cx.torch.cuda.empty_cache()
             if not args.no_config4:
-                subs["config4"] = bench_batch(cx, args, 4, max(5, min(args.steps, 10)), 2)
+                subs["config4"] = bench_batch(cx, args, 4, sub_steps, 3)
             if not args.no_config5:
                 subs["config5"] = bench_config5(cx, args, steps=sub_steps, warmup=2, with_cpu=False)
         if cx.rank == 0:

@@ -141,6 +141,12 @@ class MFCC:
     def kernel_name(self, fixed=False) -> str:
         return self._lib.mfcc_hip_kernel_name(self._h, int(fixed)).decode()
 
+    def is_fallback(self, fixed=False) -> bool:
+        """True when this parameter set runs on a generic kernel (one frame per wave, 3-6 x slower than the fused kernels
+        that cover the reference's own configurations): bench.py puts it into its line as ``config.fallback``."""
+        name = self.kernel_name(fixed)
+        return "generic" in name or name == "mfcc_fixed_kernel"
+
     def set_stream(self, stream_ptr):
         """Launch on a caller-provided hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``;
         0 / None is the HIP null stream, torch's default)."""
