@@ -20,6 +20,7 @@
 #include "kernel_fixed512.hpp"
 #include "kernel_fused1024.hpp"
 #include "kernel_fused1024_f32.hpp"
+#include "kernel_fused1024_w12.hpp"
 #include "kernel_fused512.hpp"
 #include "kernel_fused512_w12.hpp"
 #include "tables.hpp"
@@ -129,6 +130,7 @@ struct mfcc_hip_handle {
     mfcc_fused1024::Tables f1k{};          // bf16-split contraction, set lists for every rate (kernel_fused1024.hpp)
     mfcc_fused1024_f32::Tables f1k_f32{};  // fp32 contraction, one MFMA list per rate (kernel_fused1024_f32.hpp)
     bool f1k_is_f32 = false;      // which of the two forms this handle's rate runs on
+    bool f1k_w12 = false;         // the fp32 form's tables, staged as twelve waves (kernel_fused1024_w12.hpp)
     // descriptor tables of the ragged calls live in pinned host memory, two buffers used in turn: the H2D copy of
     // an asynchronous call reads buffer i while the next call fills buffer 1 - i; the call after that waits for the
     // event recorded behind buffer i's copy before it overwrites it
@@ -329,9 +331,10 @@ int build_tables(mfcc_hip_handle *h) {
     h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep);
     if (h->fused1k_ok) {
         // the fp32 form where it has a list for the rate (3 % faster there), the bf16 form everywhere else;
-        // MFCC_HIP_FUSED1024=bf16 / f32: diagnostic override for A/B runs
+        // MFCC_HIP_FUSED1024=bf16 / f32 / w12: diagnostic override for A/B runs (f32: the eight-wave staging of the fp32 form)
         const char *e = std::getenv("MFCC_HIP_FUSED1024");
-        const bool no_f32 = e && !std::strcmp(e, "bf16"), no_bf16 = e && !std::strcmp(e, "f32");
+        const bool no_f32 = e && !std::strcmp(e, "bf16"), no_bf16 = e && (!std::strcmp(e, "f32") || !std::strcmp(e, "w12"));
+        h->f1k_w12 = !(e && !std::strcmp(e, "f32"));
         h->f1k_is_f32 = !no_f32 && mfcc_fused1024_f32::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
         if (!h->f1k_is_f32)
             h->fused1k_ok = !no_bf16 && mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
@@ -456,7 +459,8 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
         if (!done && !mfcc_fused::launch(s, h->fu, h->fused_dense, static_cast<float *>(d_out), h->n_cu, h->stream))
             return MFCC_HIP_ERROR_UNSUPPORTED;
     } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
-               (h->f1k_is_f32 ? mfcc_fused1024_f32::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream)
+               (h->f1k_is_f32 ? ((h->f1k_w12 && mfcc_fused1024_w12::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream)) ||
+                                 mfcc_fused1024_f32::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream))
                               : mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream))) {
         // fused 1024/341/40 kernel launched
     } else {
@@ -1334,7 +1338,8 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (!h) return "";
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return h->fused_w12 ? mfcc_fused12::kernel_name() : mfcc_fused::kernel_name();
-    if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO) return mfcc_fused1024::kernel_name();
+    if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO)
+        return h->f1k_is_f32 && h->f1k_w12 ? mfcc_fused1024_w12::kernel_name() : mfcc_fused1024::kernel_name();
     return "mfcc_float_generic_kernel";
 }
 

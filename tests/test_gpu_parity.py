@@ -197,7 +197,7 @@ def test_fused1024_kernel_alignment_shifts_and_edges(mfcc_amd):
         view = torch.as_strided(flat, (nch, n), (stride, 1), storage_offset=base_off)
         for halo in (0, 1):
             with mfcc_amd.MFCC(**kw) as mfu, mfcc_amd.MFCC(impl="generic", **kw) as mge:
-                assert mfu.kernel_name().endswith("fused1024_kernel") and mfu.hop == 341
+                assert mfu.kernel_name().startswith("mfcc_fused1024") and mfu.hop == 341
                 assert mge.kernel_name().endswith("generic_kernel")
                 a = mfu.process(view, halo=halo).cpu().numpy()
                 b = mge.process(view, halo=halo).cpu().numpy()
@@ -218,7 +218,7 @@ def test_fused1024_other_ncep_stream_padding_and_lifter(mfcc_amd, ncep):
     ref = mf.mfcc_float_ref(pcm, n_cep=ncep, pad_mode="stream", nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
     with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=ncep, power_scale=0, pad_mode="stream") as m:
         # every coefficient count up to n_mel on the fused kernel (the reference tops keep nceptrums = nfilters)
-        assert m.kernel_name().endswith("fused1024_kernel")
+        assert m.kernel_name().startswith("mfcc_fused1024")
         got = m.process(pcm)
         many = m.process_batch([pcm[0], pcm[1][:5000], pcm[2][:1023]])
         assert np.array_equal(many[0], got[0]) and many[2].shape == (1, ncep)
@@ -266,7 +266,7 @@ def test_other_sample_rates_never_get_a_wrong_fused_kernel(mfcc_amd, sr):
             if nfft == 512:
                 assert m.kernel_name().startswith("mfcc_fused512")
             else:
-                assert m.kernel_name() == "mfcc_fused1024_kernel", sr
+                assert m.kernel_name().startswith("mfcc_fused1024"), sr
         ref = mf.mfcc_float_ref(x, nfft=nfft, hop=nfft // 3, n_mel=nmel, sample_rate=sr, power_scale=float(nfft))
         e_max, e_l2 = _err(got, ref)
         assert e_max <= TOL and e_l2 <= TOL, (sr, nfft)
@@ -284,7 +284,7 @@ def test_fused1024_schedules_of_other_rates_vs_generic_and_oracle(mfcc_amd, sr):
     view = torch.as_strided(torch.from_numpy(flat).cuda(), (nch, n), (n + 3, 1), storage_offset=5)
     kw = dict(nfft=1024, nfilters=40, nceptrums=32, samplerate=sr, power_scale=0, pad_mode="stream")
     with mfcc_amd.MFCC(**kw) as a, mfcc_amd.MFCC(impl="generic", **kw) as b:
-        assert a.kernel_name() == "mfcc_fused1024_kernel"
+        assert a.kernel_name().startswith("mfcc_fused1024")
         ga, gb = a.process(view).cpu().numpy(), b.process(view).cpu().numpy()
     for c in range(nch):
         ref = mf.mfcc_float_ref(flat[5 + c * (n + 3): 5 + c * (n + 3) + n], n_cep=32, nfft=1024, hop=341, n_mel=40,
