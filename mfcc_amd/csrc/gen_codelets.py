@@ -153,6 +153,34 @@ class Gen:
                          op_sel=[1, 1, 0], op_sel_hi=[1, 0, 1],
                          neg_lo=[0, 0 if conj else 1, 0], neg_hi=[0, 1 if conj else 0, 0])
 
+    # ---- the last layer in transposed packing: (Re(a + w b), Re(a - w b)) and (Im(a + w b), Im(a - w b))
+    def bf_t(self, a, b, w):
+        c, d = w.real, w.imag
+        y0, y1 = a.num + w * b.num, a.num - w * b.num
+        rn, im = complex(y0.real, y1.real), complex(y0.imag, y1.imag)
+        if abs(d) < 1e-15 and abs(c - 1.0) < 1e-15:
+            R = self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], rn, op_sel=[0, 0], op_sel_hi=[0, 0], neg_hi=[0, 1])
+            I = self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], im, op_sel=[1, 1], op_sel_hi=[1, 1], neg_hi=[0, 1])
+            return R, I
+        if abs(c) < 1e-15 and abs(d + 1.0) < 1e-15:          # w = -i: (ar + bi, ai - br), (ar - bi, ai + br)
+            R = self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], rn, op_sel=[0, 1], op_sel_hi=[0, 1], neg_hi=[0, 1])
+            I = self._asm("v_pk_add_f32", [("v", a.name), ("v", b.name)], im, op_sel=[1, 0], op_sel_hi=[1, 0], neg_lo=[0, 1])
+            return R, I
+        assert abs(c) > 0.15
+        u = self.rot(b, d / c)
+        k, nl, _ = self.const(c, c)
+        R = self._asm("v_pk_fma_f32", [("v", u.name), ("s", k), ("v", a.name)], rn,
+                      op_sel=[0, 0, 0], op_sel_hi=[0, 1, 0], neg_lo=[0, nl, 0], neg_hi=[0, 1 - nl, 0])
+        I = self._asm("v_pk_fma_f32", [("v", u.name), ("s", k), ("v", a.name)], im,
+                      op_sel=[1, 0, 1], op_sel_hi=[1, 1, 1], neg_lo=[0, nl, 0], neg_hi=[0, 1 - nl, 0])
+        return R, I
+
+    def power(self, R, I):
+        """(re0^2 + im0^2, re1^2 + im1^2) with the rounding of fmaf(re, re, im * im)"""
+        ew = lambda u, v: complex(u.num.real * v.num.real, u.num.imag * v.num.imag)
+        m = self._c("%s * %s" % (I.name, I.name), ew(I, I))
+        return self._c("__builtin_elementwise_fma(%s, %s, %s)" % (R.name, R.name, m.name), ew(R, R) + m.num)
+
     # ---- butterflies
     def bf(self, a, b, w):
         """(a + w b, a - w b)"""
@@ -175,6 +203,21 @@ def fft_dit(G, xs, leaf):
     out = [None] * n
     for k in range(n // 2):
         out[k], out[k + n // 2] = G.bf(ev[k], od[k], cmath.exp(-2j * math.pi * k / n))
+    return out
+
+
+def fft_dit_power(G, xs, leaf):
+    """The same transform with its LAST layer in transposed packing -- a butterfly's two outputs X[k], X[k + n/2] come
+    out as (Re X[k], Re X[k + n/2]) and (Im X[k], Im X[k + n/2]), at the same one-op-per-pair cost -- so that |X|^2 of
+    two bins is one v_pk_mul + one v_pk_fma instead of two v_mul + two v_fma.  Returns ([(P[k], P[k + n/2])], reference
+    pairs): the caller never sees the complex values."""
+    n = len(xs)
+    ev = fft_dit(G, xs[0::2], leaf)
+    od = fft_dit(G, xs[1::2], leaf)
+    out = []
+    for k in range(n // 2):
+        R, I = G.bf_t(ev[k], od[k], cmath.exp(-2j * math.pi * k / n))
+        out.append(G.power(R, I))
     return out
 
 
@@ -243,6 +286,57 @@ def gen_cfft16():
         "\n".join("    z[%d] = %s;" % (k, v.name) for k, v in enumerate(X))
     src = ("// complex 16-point DFT, natural order in and out: %d packed VALU ops\n"
            "__device__ __forceinline__ void cfft16(const v2f (&x)[16], v2f (&z)[16]) {\n%s\n}\n" % (G.ops, body))
+    return src, G.ops
+
+
+def gen_cfft16_pow():
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(16) + 1j * rng.standard_normal(16)
+    G = Gen()
+    P = fft_dit_power(G, [CV("x[%d]" % i, x[i]) for i in range(16)], lambda a, b: (G.add(a, b), G.sub(a, b)))
+    ref = np.abs(np.fft.fft(x)) ** 2
+    err = max(max(abs(v.num.real - ref[k]), abs(v.num.imag - ref[k + 8])) for k, v in enumerate(P)) / ref.max()
+    assert err < 1e-12, err
+    lines, tight = schedule(G.lines)
+    print("cfft16_pow: %d dependences closer than %d slots" % (tight, ISSUE_DISTANCE))
+    body = emit_consts(G) + "\n" + "\n".join(lines) + "\n" + \
+        "\n".join("    pp[%d] = %s;" % (k, v.name) for k, v in enumerate(P))
+    src = ("// |X[k]|^2 of the complex 16-point DFT: pp[k] = (|X[k]|^2, |X[k + 8]|^2), k = 0..7 (last layer in transposed\n"
+           "// packing, see the generator): %d packed VALU ops\n"
+           "__device__ __forceinline__ void cfft16_pow(const v2f (&x)[16], v2f (&pp)[8]) {\n%s\n}\n" % (G.ops, body))
+    return src, G.ops
+
+
+def gen_cfft32_half_pow(h):
+    rng = np.random.default_rng(13 + h)
+    x = rng.standard_normal(32) + 1j * rng.standard_normal(32)
+    G = Gen()
+    xl = [CV("xl[%d]" % i, x[i]) for i in range(16)]
+    xh = [CV("xh[%d]" % i, x[i + 16]) for i in range(16)]
+    a = []
+    for n in range(16):
+        if h == 0:
+            a.append(G.add(xl[n], xh[n]))
+        else:
+            d = G.sub(xl[n], xh[n])
+            if n == 0:
+                a.append(d)
+            elif n == 8:
+                a.append(G.mul_mi(d))
+            else:
+                a.append(G.mulc(d, cmath.exp(-2j * math.pi * n / 32)))
+    P = fft_dit_power(G, a, lambda p, q: (G.add(p, q), G.sub(p, q)))
+    ref = np.abs(np.fft.fft(x)[h::2]) ** 2
+    err = max(max(abs(v.num.real - ref[k]), abs(v.num.imag - ref[k + 8])) for k, v in enumerate(P)) / ref.max()
+    assert err < 1e-12, err
+    lines, tight = schedule(G.lines)
+    print("cfft32_h%d_pow: %d dependences closer than %d slots" % (h, tight, ISSUE_DISTANCE))
+    body = emit_consts(G) + "\n" + "\n".join(lines) + "\n" + \
+        "\n".join("    pp[%d] = %s;" % (k, v.name) for k, v in enumerate(P))
+    src = ("// |F[2m + %d]|^2 of the complex 32-point DFT of x[n] = xl[n], x[n + 16] = xh[n]: pp[m] = (m, m + 8), m = 0..7\n"
+           "// (one decimation-in-frequency step, a 16-point DFT with its last layer in transposed packing): %d packed VALU ops\n"
+           "__device__ __forceinline__ void cfft32_h%d_pow(const v2f (&xl)[16], const v2f (&xh)[16], v2f (&pp)[8]) {\n%s\n}\n"
+           % (h, G.ops, h, body))
     return src, G.ops
 
 
@@ -354,15 +448,19 @@ def main():
     b, nb = gen_cfft16()
     c0, n0 = gen_cfft32_half(0)
     c1, n1 = gen_cfft32_half(1)
+    bp, nbp = gen_cfft16_pow()
+    c0p, n0p = gen_cfft32_half_pow(0)
+    c1p, n1p = gen_cfft32_half_pow(1)
     out = ("// GENERATED by gen_codelets.py -- do not edit.  Packed-fp32 straight-line FFT codelets (see the\n"
            "// generator's docstring); every op was traced numerically against numpy.fft.\n"
            "#pragma once\n#include <hip/hip_runtime.h>\n\nnamespace mfcc_codelets {\n\n"
-           "typedef float v2f __attribute__((ext_vector_type(2)));\n\n" + a + "\n" + b + "\n" + c0 + "\n" + c1 +
+           "typedef float v2f __attribute__((ext_vector_type(2)));\n\n" + a + "\n" + b + "\n" + c0 + "\n" + c1 + "\n" + bp + "\n" + c0p + "\n" + c1p +
            "\n}  // namespace mfcc_codelets\n")
     path = os.path.join(HERE, "codelets_gen.hpp")
     with open(path, "w") as f:
         f.write(out)
-    print("rfft32_tw: %d packed ops, cfft16: %d, cfft32_h0: %d, cfft32_h1: %d -> %s" % (na, nb, n0, n1, path))
+    print("rfft32_tw: %d packed ops, cfft16: %d, cfft32_h0: %d, cfft32_h1: %d; with |X|^2: cfft16_pow %d, cfft32_h0_pow %d, "
+          "cfft32_h1_pow %d -> %s" % (na, nb, n0, n1, nbp, n0p, n1p, path))
 
 
 if __name__ == "__main__":

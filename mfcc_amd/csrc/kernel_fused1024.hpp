@@ -472,7 +472,7 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
         // ---------------- pass 2: outputs k2 = 2 m + h of the complex FFT-32 over n2, frame lo, column k1
         float pw[16];
         {
-            v2f xl[16], xh[16], z[16];
+            v2f xl[16], xh[16];
             const f32x4 *trow = reinterpret_cast<const f32x4 *>(Tt + lo * kTFrame + (4 * (wave >> 1) + q) * kTRow);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -482,10 +482,11 @@ void mfcc_fused1024_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *
                 xh[2 * i] = (v2f){b[0], b[1]};
                 xh[2 * i + 1] = (v2f){b[2], b[3]};
             }
-            if (h) mfcc_codelets::cfft32_h1(xl, xh, z);
-            else mfcc_codelets::cfft32_h0(xl, xh, z);
+            v2f pp[8];                               // (|z[m]|^2, |z[m + 8]|^2): the codelet's last layer is transposed
+            if (h) mfcc_codelets::cfft32_h1_pow(xl, xh, pp);
+            else mfcc_codelets::cfft32_h0_pow(xl, xh, pp);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) pw[m] = fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
+            for (int m = 0; m < 8; ++m) pw[m] = pp[m].x, pw[m + 8] = pp[m].y;
         }
 
         // ---------------- MFMA window (frame column = lo, K index = q): the mel contraction on bf16 pairs

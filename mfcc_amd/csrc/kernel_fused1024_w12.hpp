@@ -123,6 +123,21 @@ __device__ __forceinline__ void wait_a_burst(float (&am)[kAmel]) {
 #define MFCC_1K12_PRIO_P2 0
 #endif
 
+// Diagnostic build only (-DMFCC_1K12_STAMPS, tools/stamps1k.py): per wave, s_memtime ticks spent in up to eight
+// segments of a half-step, summed over workgroups; written to a buffer nothing else reads.
+#ifdef MFCC_1K12_STAMPS
+__device__ unsigned long long g_stamps1k[kW12Waves * 12];
+#define ST1K_BEGIN unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define ST1K(k) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_last; st_last = st_now; } while (0)
+#define ST1K_LDS(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ST1K(k); } while (0)
+#define ST1K_END do { if (lane == 0) { for (int st_k = 0; st_k < 12; ++st_k) atomicAdd(&g_stamps1k[wave * 12 + st_k], st_acc[st_k]); } } while (0)
+#else
+#define ST1K_BEGIN
+#define ST1K(k)
+#define ST1K_LDS(k)
+#define ST1K_END
+#endif
+
 template <int R>
 __global__ __launch_bounds__(64 * kW12Waves) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, float *__restrict__ out) {
@@ -172,6 +187,7 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
         const float *const amp = t.a_mel + (size_t)(2 * wi) * kAmel * 64;      // uniform; lane offset in bytes below
         const int lane4 = lane * 4;
 
+        ST1K_BEGIN
         auto pass1 = [&](int i) {
             // ---------------- pass 1: windowed real FFT-32 over n1, two batches of two frames
             __builtin_amdgcn_s_setprio(MFCC_1K12_PRIO_P1);
@@ -199,7 +215,9 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
             }
             v2f ty[16];
             float y16;
+            ST1K_LDS(0);
             mfcc_codelets::rfft32_tw(ep, wp, tw, ty, y16);
+            ST1K(1);
             {
                 // the second batch's operands fly while the first batch's columns are stored
                 const float *sp = S + (fr0 + 2) * kHop + n2 + shift;
@@ -210,6 +228,7 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
             const int need = 4 * (gi ? i + 1 : (i < n_other ? i : n_other));
             while (__hip_atomic_load(Flag + (gi ^ 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - need < 0)
                 __builtin_amdgcn_s_sleep(1);
+            ST1K(2);
             {
                 v2f *tcol0 = reinterpret_cast<v2f *>(T + fr0 * kTFrame) + n2;      // a store's lanes: consecutive n2
 #pragma unroll
@@ -223,11 +242,12 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
                 for (int k1 = 0; k1 < 16; ++k1) tcol0[k1 * (kTRow / 2)] = ty[k1];
                 V[(fr0 + 2) * kVStride + n2] = y16;
             }
+            ST1K_LDS(3);
         };
         auto pass2 = [&]() {
             // ---------------- pass 2: the complex FFT-32 over n2 of column k1 = 4 wi + q, frame lo; mel MFMAs
             __builtin_amdgcn_s_setprio(MFCC_1K12_PRIO_P2);
-            v2f xl[16], xh[16], z[16];
+            v2f xl[16], xh[16], pp[8];
             const f32x4 *trow = reinterpret_cast<const f32x4 *>(T + lo * kTFrame + (4 * wi + q) * kTRow);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -237,6 +257,7 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
                 xh[2 * i] = (v2f){b[0], b[1]};
                 xh[2 * i + 1] = (v2f){b[2], b[3]};
             }
+            ST1K_LDS(5);
             if (lane == 0) __hip_atomic_fetch_add(Flag + gi, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             float am[kAmel], pw[16];
 #pragma unroll
@@ -244,38 +265,47 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
             f32x4 acc[kBlocks] = {zero, zero, zero};
             load_a_burst<Sched<R>::N0>(am, amp, lane4);
             __builtin_amdgcn_sched_barrier(0);
-            mfcc_codelets::cfft32_h0(xl, xh, z);
+            mfcc_codelets::cfft32_h0_pow(xl, xh, pp);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) pw[m] = fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
+            for (int m = 0; m < 8; ++m) pw[m] = pp[m].x, pw[m + 8] = pp[m].y;
             __builtin_amdgcn_sched_barrier(0);         // (the wait is hoisted over the codelet otherwise)
+            ST1K(8);
             wait_a_burst(am);
+            ST1K(9);
             mel_mfmas<R, 0>(pw, am, acc);
             __builtin_amdgcn_sched_barrier(0);
+            ST1K(10);
             load_a_burst<Sched<R>::N1>(am, amp + kAmel * 64, lane4);
             __builtin_amdgcn_sched_barrier(0);
-            mfcc_codelets::cfft32_h1(xl, xh, z);
+            mfcc_codelets::cfft32_h1_pow(xl, xh, pp);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) pw[m] = fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
+            for (int m = 0; m < 8; ++m) pw[m] = pp[m].x, pw[m + 8] = pp[m].y;
             __builtin_amdgcn_sched_barrier(0);
+            ST1K(11);
             wait_a_burst(am);
             mel_mfmas<R, 1>(pw, am, acc);
 #pragma unroll
             for (int b = 0; b < kBlocks; ++b)
                 *reinterpret_cast<f32x4 *>(Q + ((wi * kBlocks + b) * 64 + lane) * 4) = acc[b];
+            ST1K_LDS(6);
         };
         lds_barrier();                                 // prologue: S_A(0), S_B(0), the constants and the counters are in LDS
+        ST1K(7);
         int bars = last_h + 1;                         // every wave of the workgroup passes this many barriers
         if (gi) {                                      // h = 0: group B idles
             lds_barrier();
             --bars;
         }
         for (int i = 0; i < n_mine; ++i) {
+            ST1K(7);
             pass1(i);
             lds_barrier();
+            ST1K(4);
             pass2();
             lds_barrier();
             bars -= 2;
         }
+        ST1K_END;
         for (; bars > 0; --bars) lds_barrier();
     } else if (wi < 2) {
         // =========================================================================== parkers (waves 8, 9)
@@ -310,7 +340,9 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
             have_b = true;
         }
         lds_barrier();
+        ST1K_BEGIN
         for (int h = 0; h <= last_h; ++h) {
+            ST1K(4);
             // a group's window is rewritten while that group runs pass 2; it reads it in its next pass 1.  The next
             // window of the same stream is fetched right behind: two half-steps of lead over its park
             if (h & 1) {
@@ -332,8 +364,10 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
                     have_b = true;
                 }
             }
+            ST1K_LDS(0);
             lds_barrier();
         }
+        ST1K_END;
     } else if (wi == 2) {
         // =========================================================================== column 16 (wave 10)
         __builtin_amdgcn_s_setprio(3);
@@ -344,7 +378,9 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
             a2[i] = t.a_extra[(2 * kAextra + i) * 64 + lane];
         }
         lds_barrier();
+        ST1K_BEGIN
         for (int h = 0; h <= last_h; ++h) {
+            ST1K(4);
             // the group in pass 2 at h: A (tile (h - 1) / 2) for odd h, B (tile h / 2 - 1) for even h >= 2
             const int gi = (h & 1) ? 0 : 1;
             const int k = (h & 1) ? (h - 1) / 2 : h / 2 - 1;
@@ -378,8 +414,10 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
                 for (int b = 0; b < kBlocks; ++b)
                     *reinterpret_cast<f32x4 *>(Q + ((4 * kBlocks + b) * 64 + lane) * 4) = acc[b];
             }
+            ST1K_LDS(0);
             lds_barrier();
         }
+        ST1K_END;
     } else {
         // =========================================================================== tail (wave 11)
         __builtin_amdgcn_s_setprio(3);
@@ -389,7 +427,9 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
         const int lane_off = lo * t.n_cep + 4 * q;
         Cursor ta = cursor_of(s, g, va), tb = cursor_of(s, g, vb);
         lds_barrier();
+        ST1K_BEGIN
         for (int h = 0; h <= last_h; ++h) {
+            ST1K(4);
             // the group that was in pass 2 at h - 1: A (tile h / 2 - 1) for even h, B (tile (h - 3) / 2) for odd h
             const int gi = (h & 1) ? 1 : 0;
             const int k = (h & 1) ? (h - 3) / 2 : h / 2 - 1;
@@ -417,8 +457,10 @@ void mfcc_fused1024_w12_kernel(mfcc_k::StreamDesc s, Tables t, LaunchGeom g, flo
                     advance(ta, g);
                 }
             }
+            ST1K_LDS(0);
             lds_barrier();
         }
+        ST1K_END;
     }
 }
 

@@ -758,7 +758,7 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
         // ---------------- pass 2: complex FFT-16 over n2 for frame lo, column k1 = 4 wave + q
         float pw[16];                            // |X|^2 at bin(wave, q, k2)
         {
-            mfcc_codelets::v2f x[16], z[16];
+            mfcc_codelets::v2f x[16];
             const f32x4 *trow = reinterpret_cast<const f32x4 *>(Tt + lo * kTFrame + (4 * wave + q) * kTRow);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -767,9 +767,10 @@ void mfcc_fused512_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g, flo
                 x[2 * i + 1] = (mfcc_codelets::v2f){a[2], a[3]};
             }
             MFCC_STAMP(1);
-            mfcc_codelets::cfft16(x, z);
+            mfcc_codelets::v2f pp[8];                // (|z[k2]|^2, |z[k2 + 8]|^2): the codelet's last layer is transposed
+            mfcc_codelets::cfft16_pow(x, pp);
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
+            for (int k2 = 0; k2 < 8; ++k2) pw[k2] = pp[k2].x, pw[k2 + 8] = pp[k2].y;
         }
         if constexpr (DCX) {
             if (wave == 0) {                     // lanes (frame lo, k1 = 0) hold bin 0 in pw[0]

@@ -344,7 +344,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
             __builtin_amdgcn_s_setprio(MFCC_W12_PRIO_P2);
             float pw[16];
             {
-                v2f x[16], z[16];
+                v2f x[16];
                 const f32x4 *trow = reinterpret_cast<const f32x4 *>(T + lo * kTFrame + (4 * wi + q) * kTRow);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -352,9 +352,10 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     x[2 * i] = (v2f){a[0], a[1]};
                     x[2 * i + 1] = (v2f){a[2], a[3]};
                 }
-                mfcc_codelets::cfft16(x, z);
+                v2f pp[8];                           // (|z[k2]|^2, |z[k2 + 8]|^2): the codelet's last layer is transposed
+                mfcc_codelets::cfft16_pow(x, pp);
 #pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) pw[k2] = fmaf(z[k2].x, z[k2].x, z[k2].y * z[k2].y);
+                for (int k2 = 0; k2 < 8; ++k2) pw[k2] = pp[k2].x, pw[k2 + 8] = pp[k2].y;
             }
             PowerBf pb;
             split_power(pw, pb);

@@ -1685,6 +1685,15 @@ int mfcc_hip_debug_read_stamps12(unsigned long long *dst) {
 }
 #endif
 
+#ifdef MFCC_1K12_STAMPS
+extern "C" int mfcc_hip_debug_read_stamps1k(unsigned long long *dst) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(mfcc_fused1024_w12::g_stamps1k), sizeof(unsigned long long) * 144) != hipSuccess)
+        return MFCC_HIP_ERROR_OTHER;
+    unsigned long long z[144] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mfcc_fused1024_w12::g_stamps1k), z, sizeof z) != hipSuccess) return MFCC_HIP_ERROR_OTHER;
+    return MFCC_HIP_SUCCESS;
+}
+#endif
 #ifdef MFCC_FUSED_STAMPS
 // diagnostic build only: copy out and clear the per-phase cycle sums of the fused kernel
 int mfcc_hip_debug_read_stamps(unsigned long long *dst) {
