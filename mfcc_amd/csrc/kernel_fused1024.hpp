@@ -121,6 +121,8 @@ struct Tables {
     const float *a_extra;  // [3 roles][kAextra][64]  role 0: DCT rows 0..15; role 1 / 2: column-16 DFT (8) + its mel weights (6)
     const float *a_dct_hi; // [2][12][64]  DCT rows of coefficients 16..31 and 32..47 (fetched per tile, only when n_cep > 16:
                            // the kernel has no registers to keep them)
+    const uint32_t *a_bf4; // the same mel weights as [8 waves][sets][hi, lo][64 lanes][4 dwords]: one 16-byte load per
+                           // lane and operand for the twelve-wave form, which streams them (kernel_fused1024_w12.hpp)
     int n_cep;
 };
 
@@ -241,6 +243,11 @@ inline bool build_tables_for(int variant, int sample_rate, double power_scale, d
     put(aext.data(), aext.size() * 4);
     put(adct.data(), adct.size() * 4);
     put(abf.data(), abf.size() * 4);
+    std::vector<uint32_t> abf4(abf.size());
+    for (size_t op = 0; op < abf.size() / 256; ++op)
+        for (int d = 0; d < 4; ++d)
+            for (int l = 0; l < 64; ++l) abf4[op * 256 + l * 4 + d] = abf[op * 256 + d * 64 + l];
+    put(abf4.data(), abf4.size() * 4);
     return true;
 }
 
@@ -260,6 +267,7 @@ inline void bind_tables(const char *b, int n_cep, int variant, Tables &t) {
     t.a_extra = f;    f += 3 * kAextra * 64;
     t.a_dct_hi = f;   f += 2 * 12 * 64;
     t.a_bf = reinterpret_cast<const uint32_t *>(f);
+    t.a_bf4 = t.a_bf + (size_t)kWaves * sets_view(variant).n * 2 * 256;
 }
 
 // ---- device (helpers shared in spirit with kernel_fused512.hpp; kept local so the two kernels stay independent)

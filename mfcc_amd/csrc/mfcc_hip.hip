@@ -330,11 +330,13 @@ int build_tables(mfcc_hip_handle *h) {
     int f1k_var = 0;
     h->fused1k_ok = mfcc_fused1024::supported(r.nfft, r.hop, r.n_mel, r.n_cep);
     if (h->fused1k_ok) {
-        // the fp32 form where it has a list for the rate (3 % faster there), the bf16 form everywhere else;
-        // MFCC_HIP_FUSED1024=bf16 / f32 / w12: diagnostic override for A/B runs (f32: the eight-wave staging of the fp32 form)
+        // Default: the twelve-wave staging with the bf16-split contraction (kernel_fused1024_w12.hpp), every rate.
+        // MFCC_HIP_FUSED1024 is a diagnostic override for A/B runs -- f32 / bf16: the eight-wave lockstep staging of
+        // either contraction; w12 / w12bf: the twelve-wave staging of either (fp32: the five rates it has lists for)
         const char *e = std::getenv("MFCC_HIP_FUSED1024");
-        const bool no_f32 = e && !std::strcmp(e, "bf16"), no_bf16 = e && (!std::strcmp(e, "f32") || !std::strcmp(e, "w12"));
-        h->f1k_w12 = !(e && !std::strcmp(e, "f32"));
+        auto is = [&](const char *v) { return e && !std::strcmp(e, v); };
+        const bool no_f32 = !(is("f32") || is("w12")), no_bf16 = is("f32") || is("w12");
+        h->f1k_w12 = !(is("f32") || is("bf16"));
         h->f1k_is_f32 = !no_f32 && mfcc_fused1024_f32::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
         if (!h->f1k_is_f32)
             h->fused1k_ok = !no_bf16 && mfcc_fused1024::build_tables(r.sample_rate, r.power_scale, r.lifter, r.n_cep, f1k_blob, f1k_var);
@@ -461,7 +463,8 @@ int launch(mfcc_hip_handle *h, bool fixed, const void *d_pcm, size_t n, size_t s
     } else if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO &&
                (h->f1k_is_f32 ? ((h->f1k_w12 && mfcc_fused1024_w12::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream)) ||
                                  mfcc_fused1024_f32::launch(s, h->f1k_f32, static_cast<float *>(d_out), h->n_cu, h->stream))
-                              : mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream))) {
+                              : ((h->f1k_w12 && mfcc_fused1024_w12bf::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)) ||
+                                 mfcc_fused1024::launch(s, h->f1k, static_cast<float *>(d_out), h->n_cu, h->stream)))) {
         // fused 1024/341/40 kernel launched
     } else {
         long long blocks = (total + mfcc_k::kWavesPerBlock - 1) / mfcc_k::kWavesPerBlock;
@@ -1339,7 +1342,8 @@ const char *mfcc_hip_kernel_name(const mfcc_hip_handle *h, int fixed) {
     if (fixed) return h->fixed512_ok ? mfcc_fixed512::kernel_name() : "mfcc_fixed_kernel";
     if (use_fused(h)) return h->fused_w12 ? mfcc_fused12::kernel_name() : mfcc_fused::kernel_name();
     if (h->fused1k_ok && h->r.float_impl == MFCC_HIP_IMPL_AUTO)
-        return h->f1k_is_f32 && h->f1k_w12 ? mfcc_fused1024_w12::kernel_name() : mfcc_fused1024::kernel_name();
+        return !h->f1k_w12 ? mfcc_fused1024::kernel_name()
+                           : h->f1k_is_f32 ? mfcc_fused1024_w12::kernel_name() : mfcc_fused1024_w12bf::kernel_name();
     return "mfcc_float_generic_kernel";
 }
 
