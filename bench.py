@@ -247,8 +247,9 @@ def pipe_clocks():
 
 
 # packed fp32 ops per frame (codelets_gen.hpp op counts x lanes per frame / 64): the 512 kernel runs rfft32_tw (158)
-# and cfft16 (74) on 16 lanes per frame each; the 1024 kernel rfft32_tw on 32 lanes, cfft32_h0 (90) and _h1 (119) on 16 each
-PK_PER_FRAME = {"mfcc_fused512": (158 + 74) * 16 / 64.0, "mfcc_fused1024": (158 * 32 + (90 + 119) * 16) / 64.0}
+# and cfft16_pow (90: the transform and |X|^2) on 16 lanes per frame each; the 1024 kernel rfft32_tw on 32 lanes,
+# cfft32_h0_pow (106) and _h1_pow (135) on 16 each
+PK_PER_FRAME = {"mfcc_fused512": (158 + 90) * 16 / 64.0, "mfcc_fused1024": (158 * 32 + (106 + 135) * 16) / 64.0}
 
 
 def profile_figures(kernel_name, frames):

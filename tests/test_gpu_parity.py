@@ -552,3 +552,21 @@ def test_ragged_batch_many_short_utterances(mfcc_amd):
         for i in (0, 17, 299):
             assert got[i].shape == (m.num_frames(160000), 13) == (939, 13)
             assert np.array_equal(got[i], m.process(utts[i]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,name", [("w12bf", "mfcc_fused1024_w12bf_kernel"), ("w12", "mfcc_fused1024_w12_kernel"),
+                                       ("f32", "mfcc_fused1024_kernel"), ("bf16", "mfcc_fused1024_kernel")])
+def test_fused1024_every_staging_of_the_kernel_against_the_oracle(mfcc_amd, monkeypatch, form, name):
+    """The 1024 path has four forms -- twelve waves or eight in lockstep, the mel contraction on bf16-split or fp32 matrix
+    instructions; the handle takes the twelve-wave bf16 form, MFCC_HIP_FUSED1024 (read when a handle is made) picks another
+    for A/B runs.  All of them are held to the float contract here: ragged length, unaligned start, two channels."""
+    monkeypatch.setenv("MFCC_HIP_FUSED1024", form)
+    x = np.stack([mf.synth_pcm(16 * 341 * 7 + 1024 + 77, seed=11), mf.synth_pcm(16 * 341 * 7 + 1024 + 77, seed=12)])
+    with mfcc_amd.MFCC(nfft=1024, nfilters=40, nceptrums=13, power_scale=0) as m:
+        assert m.kernel_name() == name
+        got = np.asarray(m.process(x))
+    for c in range(2):
+        ref = mf.mfcc_float_ref(x[c], nfft=1024, hop=341, n_mel=40, power_scale=1024.0)
+        e_max, e_l2 = _err(got[c], ref)
+        assert e_max <= TOL and e_l2 <= TOL, (form, c)
