@@ -28,16 +28,18 @@ run("float 512 @44.1 kHz (dense sets + exact integer DC bin, 12-wave)", samplera
 run("float 512 @48 kHz (dense sets + exact integer DC bin, 12-wave)", samplerate=48000, **base)
 run("float 512 / 16 filters (constructor default)", nfft=512, nfilters=16, nceptrums=16)
 k1 = dict(nfft=1024, nfilters=40, power_scale=0)
-run("float 1024/341/40/13 @16 kHz (config 4 kernel: fp32 lists)", nceptrums=13, **k1)
-os.environ["MFCC_HIP_FUSED1024"] = "bf16"
-run("same, bf16 set-list form (MFCC_HIP_FUSED1024=bf16)", nceptrums=13, **k1)
+run("float 1024/341/40/13 @16 kHz (config 4 kernel: twelve waves, bf16-split)", nceptrums=13, **k1)
+for form, what in (("w12", "twelve waves, fp32 lists"), ("f32", "eight waves in lockstep, fp32 lists"),
+                   ("bf16", "eight waves in lockstep, bf16-split")):
+    os.environ["MFCC_HIP_FUSED1024"] = form
+    run("same, %s (MFCC_HIP_FUSED1024=%s)" % (what, form), nceptrums=13, **k1)
 os.environ.pop("MFCC_HIP_FUSED1024")
 run("float 1024/341/40/32", nceptrums=32, **k1)
 run("float 1024/341/40/40 (all coefficients)", nceptrums=40, **k1)
 run("float 1024 @8 kHz", nceptrums=13, samplerate=8000, **k1)
 run("float 1024 @32 kHz", nceptrums=13, samplerate=32000, **k1)
-run("float 1024 @44.1 kHz (bf16 set lists; round 2: generic kernel)", nceptrums=13, samplerate=44100, **k1)
-run("float 1024 @48 kHz (bf16 set lists; round 2: generic kernel)", nceptrums=13, samplerate=48000, **k1)
+run("float 1024 @44.1 kHz (round 2: generic kernel)", nceptrums=13, samplerate=44100, **k1)
+run("float 1024 @48 kHz (round 2: generic kernel)", nceptrums=13, samplerate=48000, **k1)
 run("float 1024 @48 kHz, generic kernel", nceptrums=13, samplerate=48000, impl="generic", **k1)
 run("fixed 512/32/13 (config 3 kernel)", fixed=True, pad_mode="stream", **base)
 run("fixed 512/16/16 (constructor default)", fixed=True, pad_mode="stream", nfft=512, nfilters=16, nceptrums=16)
