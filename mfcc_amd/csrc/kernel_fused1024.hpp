@@ -25,13 +25,14 @@
 //    j' = 0..7, role 2: j' = 8..15; 8 MFMAs + their mel MFMAs each); role 0 finishes the previous tile (log2, DCT-II as 12
 //    fp32 MFMAs per 16 coefficients, store) and neither fetches nor parks samples.
 //
-// This form serves every sample rate and coefficient count.  At the five rates round 2's fp32 lists exist for (8, 11.025, 16,
-// 22.05, 32 kHz) the handle takes kernel_fused1024_f32.hpp instead, which is 3 % faster there (A/B in one box session: in
-// these lockstep phases the bf16 split's 48 extra vector instructions per wave and tile cost more than the shorter matrix
-// instructions give back).  What else was built and measured this round, and dropped (profiles/r03_notes.md):
-// 8-frame tiles in two 4-wave workgroups per CU (every per-tile cost twice, MFMAs half empty: 260 vector instructions per
-// frame against 195, 9-13 % slower), and producer / consumer waves on the 16-frame tile (pass 1 of tile k + 1 in registers
-// beside pass 2 of tile k: the stores of T behind the barrier are an LDS-bound interval nothing overlaps, 12 % slower).
+// This form serves every sample rate and coefficient count.  Since the second half of round 3 this file is (a) the tables, set
+// lists and helpers of the kernel that runs -- the TWELVE-wave staging of this contraction, kernel_fused1024_w12.hpp
+// (mfcc_fused1024_w12bf_kernel: 1.00 ms against 1.36 for the kernel below on config 4's shape) -- and (b) the eight-wave
+// LOCKSTEP staging below, an A/B form (MFCC_HIP_FUSED1024=bf16).  What else was built and measured in round 3 and dropped
+// (DESIGN.md 4.2): 8-frame tiles in two 4-wave workgroups per CU (every per-tile cost twice, MFMAs half empty: 260 vector
+// instructions per frame against 195, 9-13 % slower), and producer / consumer waves on the 16-frame tile (pass 1 of tile k + 1
+// in registers beside pass 2 of tile k: the stores of T behind the barrier are an LDS-bound interval nothing overlaps, 12 %
+// slower).
 #pragma once
 
 #include <hip/hip_runtime.h>

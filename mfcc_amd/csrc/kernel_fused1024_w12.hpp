@@ -33,6 +33,10 @@
 //   column 16 at h: the group in pass 2 (its V was written in h - 1); partial sums to Q slot 4 of the group
 //   tail at h: the group that was in pass 2 at h - 1
 // LDS 159 KB: T, per group V + Q (5 slots x 3 blocks) + S, the window / twiddle constants, two counters.
+//
+// Two kernels in this file: mfcc_fused1024_w12_kernel<R> (this namespace: the fp32 lists of kernel_fused1024_f32.hpp, five
+// sample rates, an A/B form: MFCC_HIP_FUSED1024=w12) and, at the end, mfcc_fused1024_w12bf_kernel<VAR> (the bf16-split set
+// lists of kernel_fused1024.hpp, every sample rate): the one a handle runs, 1.5 % ahead of the other at 16 kHz.
 #pragma once
 
 #include "kernel_fused1024.hpp"
