@@ -145,6 +145,10 @@ struct FusedTables {
     // exact in int32.  [17 k-blocks][64 lanes][4 dwords] A operands; dc_consts = {2^-B, lo, hi of 128 sum(C) = hi 2^28 + lo}
     const uint32_t *a_dc_i8;
     const double *dc_consts;
+    // the DCT rows as bf16 pairs for the twelve-wave kernel's tail: [2 M tiles (coefficients 0..15, 16..31)][hi, lo][4 dwords]
+    // [64 lanes]; lane (row = l & 15, q = l >> 4) holds D[16 tile + row][f(q, j)], j = 0..7, K slot 8 q + j <-> filter
+    // f(q, j) = 4 q + j (j < 4) or 16 + 4 q + j - 4: the order in which a lane of the tail holds its eight log-mel values
+    const uint32_t *a_dct_bf;
     int n_cep;
     int n_mel;            // 32, or 16: block 1 does not exist (its zero sums must not reach the DCT as -inf * 0)
 };
@@ -374,6 +378,37 @@ inline bool build_tables(int sample_rate, double power_scale, double lifter, int
         blob.resize(o2 + sizeof(consts));
         std::memcpy(blob.data() + o2, consts, sizeof(consts));
     }
+    {
+        auto bf16_round = [](float v) -> uint32_t {                          // round to nearest even, like v_cvt_pk_bf16_f32
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return u >> 16;
+        };
+        auto bf16_val = [](uint32_t h) -> float {
+            uint32_t u = h << 16;
+            float v;
+            std::memcpy(&v, &u, 4);
+            return v;
+        };
+        std::vector<float> adct(size_t(2) * 2 * 256, 0.0f);                  // uint32 payload, moved as floats
+        for (int tile = 0; tile < 2; ++tile)
+            for (int l = 0; l < 64; ++l) {
+                uint32_t hi[8], lo[8];
+                for (int j = 0; j < 8; ++j) {
+                    const int coeff = 16 * tile + (l & 15), q = l >> 4, filt = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+                    const float w = (coeff < n_cep && filt < n_mel) ? float(dd[size_t(coeff) * n_mel + filt]) : 0.0f;
+                    hi[j] = bf16_round(w);
+                    lo[j] = bf16_round(w - bf16_val(hi[j]));
+                }
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t vh = hi[2 * d] | (hi[2 * d + 1] << 16), vl = lo[2 * d] | (lo[2 * d + 1] << 16);
+                    std::memcpy(&adct[(size_t(tile) * 2 + 0) * 256 + d * 64 + l], &vh, 4);
+                    std::memcpy(&adct[(size_t(tile) * 2 + 1) * 256 + d * 64 + l], &vl, 4);
+                }
+            }
+        put(adct);
+    }
     return true;
 }
 
@@ -401,6 +436,8 @@ inline void bind_tables(const char *b, int n_cep, int n_mel, bool dense, bool dc
     t.a_dc_i8 = reinterpret_cast<const uint32_t *>(f);
     f += 17 * 64 * 4;
     t.dc_consts = reinterpret_cast<const double *>(f);
+    f += 6;
+    t.a_dct_bf = reinterpret_cast<const uint32_t *>(f);
 }
 
 // ---- device

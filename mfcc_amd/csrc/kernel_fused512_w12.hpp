@@ -12,7 +12,9 @@
 //   waves 4..7   group B: the four workers of ANOTHER tile, half a period behind A
 //   waves 8, 9   fetch the sample windows from HBM one half-step ahead and park them (pre-emphasised fp32)
 //   wave  10     column 16 of the group that is in pass 2: 16 x 16 DFT + its mel contribution (fp32 MFMAs)
-//   wave  11     the tail of the tile that finished pass 2 in the previous half-step: log2, DCT-II, store
+//   wave  11     the tail of the tile that finished pass 2 in the previous half-step: log2, DCT-II (on bf16-split matrix
+//                instructions since round 3: three independent v_mfma_f32_16x16x32_bf16 per 16 coefficients instead of
+//                eight fp32 ones that block the SIMD; frames with a -inf band take the fp32 chain), store
 //
 // Waves i, i + 4 and i + 8 share SIMD i's slot (cyclic placement): one worker in pass 1, one in pass 2, one helper.
 // Registers: a worker without the helpers' state needs 156 VGPRs (164 with the dense mel sets).
@@ -228,6 +230,9 @@ struct TileStream {
     __device__ __forceinline__ Window window() const { return window_of(c, gl); }
 };
 
+#ifndef MFCC_W12_DCT_BF16
+#define MFCC_W12_DCT_BF16 1
+#endif
 #ifndef MFCC_W12_PRIO_P1
 #define MFCC_W12_PRIO_P1 1
 #endif
@@ -567,6 +572,16 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
         float ax[kAextra];
 #pragma unroll
         for (int i = 0; i < kAextra; ++i) ax[i] = t.a_extra[(0 * kAextra + i) * 64 + lane];
+#if MFCC_W12_DCT_BF16
+        u32x4 dct_h[2], dct_l[2];
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dct_h[tile][d] = t.a_dct_bf[((size_t)tile * 2 + 0) * 256 + d * 64 + lane];
+                dct_l[tile][d] = t.a_dct_bf[((size_t)tile * 2 + 1) * 256 + d * 64 + lane];
+            }
+#endif
         const int lane_off = lo * t.n_cep + 4 * q;
         TileStream<RAGGED> ta, tb;
         ta.start(s, g, rag, va, gv, t.n_cep, out);
@@ -627,6 +642,71 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     l1[r] = __builtin_amdgcn_logf(m1[r]);
                 }
                 if (t.n_mel <= 16) l1 = zero;          // no filters 16..31 (uniform)
+#if MFCC_W12_DCT_BF16
+                // The DCT on bf16-split matrix instructions: K = 32 is the 32 log-mel values of a frame, so an M tile of 16
+                // coefficients is ONE v_mfma_f32_16x16x32_bf16 per term (3 of 16 clocks, which the workers of this SIMD can
+                // issue beside) instead of 8 fp32 ones of 32 clocks each, during which they issue nothing.  A -inf (a
+                // silent band) would split into (-inf, NaN) and turn c0 = -inf into NaN -- in its own frame only, the
+                // columns of a matrix product do not mix: a tile that holds one runs the fp32 chain as well and the frames
+                // with a -inf take its results (a frame's bits do not depend on what else is in its tile).
+                const float lmin = fminf(fminf(__builtin_fminf(l0[0], l0[1]), __builtin_fminf(l0[2], l0[3])),
+                                         fminf(__builtin_fminf(l1[0], l1[1]), __builtin_fminf(l1[2], l1[3])));
+                const unsigned long long special = __builtin_amdgcn_ballot_w64(!(lmin > -3.0e38f));
+                u32x4 bh, bl;
+                {
+                    uint32_t hi, lw;
+                    split_bf16_pair(l0[0], l0[1], hi, lw); bh[0] = hi; bl[0] = lw;
+                    split_bf16_pair(l0[2], l0[3], hi, lw); bh[1] = hi; bl[1] = lw;
+                    split_bf16_pair(l1[0], l1[1], hi, lw); bh[2] = hi; bl[2] = lw;
+                    split_bf16_pair(l1[2], l1[3], hi, lw); bh[3] = hi; bl[3] = lw;
+                }
+                // THREE INDEPENDENT products per M tile, summed afterwards.  As one accumulator chain (each
+                // v_mfma_f32_16x16x32_bf16 taking the one before it as SrcC, back to back, the compiler's one s_nop between)
+                // the sums came out wrong now and then -- 150-270 of 3 530 tiles per run, not repeatable, mostly the tile's
+                // last column -- with the conversions in asm or in plain C and with any number of wait states around the chain:
+                // what the dependent gfx950 matrix instruction needs is not what hipcc 7.2 gives it.  Everywhere else in
+                // these kernels consecutive matrix instructions never share an accumulator (term-major order).
+                const f32x4 dA = MFCC_MFMA_BF(dct_h[0], bh, zero), dB = MFCC_MFMA_BF(dct_h[0], bl, zero);
+                const f32x4 dC = MFCC_MFMA_BF(dct_l[0], bh, zero);
+                f32x4 d = (dA + dB) + dC, e = zero;
+                if (t.n_cep > 16) {
+                    const f32x4 eA = MFCC_MFMA_BF(dct_h[1], bh, zero), eB = MFCC_MFMA_BF(dct_h[1], bl, zero);
+                    const f32x4 eC = MFCC_MFMA_BF(dct_l[1], bh, zero);
+                    e = (eA + eB) + eC;
+                }
+                if (special != 0) {                    // uniform, rare
+                    f32x4 d0 = zero, d1 = zero, e0 = zero, e1 = zero;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        d0 = MFCC_MFMA(ax[r], l0[r], d0);
+                        d1 = MFCC_MFMA(ax[4 + r], l1[r], d1);
+                        e0 = MFCC_MFMA(ax[8 + r], l0[r], e0);
+                        e1 = MFCC_MFMA(ax[12 + r], l1[r], e1);
+                    }
+                    // this lane's frame is column lo: its 32 values sit in lanes lo, lo + 16, lo + 32, lo + 48
+                    const bool mine = ((special >> lo) & 0x0001000100010001ull) != 0;
+                    if (mine) {
+                        d = d0 + d1;
+                        e = e0 + e1;
+                    }
+                }
+                // (not `TileStream &c = gi ? tb : ta`: a reference picked at run time puts both walks into scratch)
+                auto finish = [&](TileStream<RAGGED> &c) {
+                    const long long fr0 = (long long)c.c.t_in * kTile;
+                    const long long rows_left = c.sl.frames_per_ch - fr0;
+                    float *o = c.outp + ((long long)c.c.ch * c.sl.frames_per_ch + fr0) * t.n_cep + lane_off;
+                    if (lo < rows_left) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (4 * q + r < t.n_cep) o[r] = d[r];
+                            if (16 + 4 * q + r < t.n_cep) o[16 + r] = e[r];
+                        }
+                    }
+                    c.next(s, rag, t.n_cep, out);
+                };
+                if (gi) finish(tb);
+                else finish(ta);
+#else
                 f32x4 d0 = zero, d1 = zero;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -640,6 +720,7 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 };
                 if (gi) finish(tb);
                 else finish(ta);
+#endif
             }
             ta.prefetch(rag);
             tb.prefetch(rag);
