@@ -660,15 +660,15 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                     split_bf16_pair(l1[0], l1[1], hi, lw); bh[2] = hi; bl[2] = lw;
                     split_bf16_pair(l1[2], l1[3], hi, lw); bh[3] = hi; bl[3] = lw;
                 }
-                // THREE INDEPENDENT products per M tile, summed afterwards.  Written as one accumulator chain (each product
-                // taking the one before it as SrcC, the second M tile's products and their uniform branches in between) this
-                // tail gave wrong sums in 150-270 of 3 530 tiles per run, not repeatably, mostly the tile's last column --
-                // with the conversions in asm or in plain C, with any number of wait states around the chain.  The chain in
-                // isolation is fine (tools/mfma_chain_probe.hip: back to back, with those branches, with the register overlap
-                // the compiler had chosen, alone and beside eleven busy waves -- 0 of 1.6e10 values differ), so the cause was
-                // in this kernel's code around it and was NOT found; this form is the one the tests, the soak and repeated
-                // full-size comparisons with the fp32 tail pass.  (Every other contraction of these kernels is term-major:
-                // consecutive matrix instructions never share an accumulator.)
+                // THREE INDEPENDENT products per M tile, summed afterwards.  Written as `d = mfma(.., 0); if (n_cep > 16) e =
+                // mfma(.., 0); d = mfma(.., d); if (n_cep > 16) e = mfma(.., e); ...` -- an accumulator chain with the second M
+                // tile's products and their UNIFORM BRANCHES between its links -- this tail gave wrong sums in 150-270 of 3 530
+                // tiles per run, not repeatably, mostly the tile's last column (asm or plain-C conversions, any number of wait
+                // states around it).  The same chain without the branches between its links is right, and so is this form
+                // (tools/dbg_tail.py on builds of each).  The failing instruction sequence in isolation is right too
+                // (tools/mfma_chain_probe.hip: 0 of 1.6e10 values, alone, beside eleven busy waves, at priority 3), so what it
+                // takes beyond a taken branch between two dependent matrix instructions was not isolated.  Every other
+                // contraction of these kernels is term-major: consecutive matrix instructions never share an accumulator.
                 const f32x4 dA = MFCC_MFMA_BF(dct_h[0], bh, zero), dB = MFCC_MFMA_BF(dct_h[0], bl, zero);
                 const f32x4 dC = MFCC_MFMA_BF(dct_l[0], bh, zero);
                 f32x4 d = (dA + dB) + dC, e = zero;

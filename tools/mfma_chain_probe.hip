@@ -23,6 +23,7 @@ __global__ __launch_bounds__(768) void probe(int iters, int ncep, unsigned *mism
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     unsigned bad = 0;
     float junk = 0.f;
+    if (wave == 11 && !ALONE) __builtin_amdgcn_s_setprio(3);     // the tail wave runs at the highest priority
     for (int it = 0; it < iters; ++it) {
         if (wave == 11 || ALONE) {
             u32x4 a[3], b[3];
@@ -49,11 +50,18 @@ __global__ __launch_bounds__(768) void probe(int iters, int ncep, unsigned *mism
             } else {
                 // ... with the uniform branches the tail had between them (a second M tile that n_cep <= 16 skips)
                 f32x4 e = zero;
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));   // operands are in registers
+                __builtin_amdgcn_sched_barrier(0);
                 c = MFMA_BF(a[0], b[0], zero);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ncep > 16) e = MFMA_BF(a[1], b[0], zero);
+                __builtin_amdgcn_sched_barrier(0);
                 c = MFMA_BF(a[1], b[1], c);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ncep > 16) e = MFMA_BF(a[2], b[1], e);
+                __builtin_amdgcn_sched_barrier(0);
                 c = MFMA_BF(a[2], b[2], c);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ncep > 16) e = MFMA_BF(a[0], b[2], e);
                 junk += e[0] + e[3];
             }
