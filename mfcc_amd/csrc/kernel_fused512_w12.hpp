@@ -666,9 +666,10 @@ void mfcc_fused512_w12_kernel(mfcc_k::StreamDesc s, FusedTables t, LaunchGeom g,
                 // tiles per run, not repeatably, mostly the tile's last column (asm or plain-C conversions, any number of wait
                 // states around it).  The same chain without the branches between its links is right, and so is this form
                 // (tools/dbg_tail.py on builds of each).  The failing instruction sequence in isolation is right too
-                // (tools/mfma_chain_probe.hip: 0 of 1.6e10 values, alone, beside eleven busy waves, at priority 3), so what it
-                // takes beyond a taken branch between two dependent matrix instructions was not isolated.  Every other
-                // contraction of these kernels is term-major: consecutive matrix instructions never share an accumulator.
+                // (tools/mfma_chain_probe.hip: compiled or written by hand with NO wait state behind the branch target, alone,
+                // beside eleven busy waves, at priority 3: 0 of 1.6e10 values), so the dependent matrix instruction is not the
+                // culprit and what is was not isolated.  Every other contraction of these kernels is term-major: consecutive
+                // matrix instructions never share an accumulator.
                 const f32x4 dA = MFCC_MFMA_BF(dct_h[0], bh, zero), dB = MFCC_MFMA_BF(dct_h[0], bl, zero);
                 const f32x4 dC = MFCC_MFMA_BF(dct_l[0], bh, zero);
                 f32x4 d = (dA + dB) + dC, e = zero;

@@ -17,7 +17,7 @@ __device__ __forceinline__ uint32_t bf16_pair(int x, int y) {           // two s
     return (__float_as_uint((float)x) >> 16) | (__float_as_uint((float)y) & 0xffff0000u);
 }
 
-template <bool ALONE, bool OVERLAP>
+template <bool ALONE, bool OVERLAP, int NOPS = -1>
 __global__ __launch_bounds__(768) void probe(int iters, int ncep, unsigned *mismatches, float *sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -38,7 +38,30 @@ __global__ __launch_bounds__(768) void probe(int iters, int ncep, unsigned *mism
             // the chain, exactly as the tail had it: nothing scheduled in between -- and (OVERLAP) with the register
             // assignment the compiler had chosen there: the THIRD instruction's destination is the SECOND's B operand
             f32x4 c;
-            if (OVERLAP) {
+            if (NOPS >= 0) {
+                // the tail's sequence by hand: producer, two vector moves, a TAKEN branch over the other tile's product, NOPS wait
+                // states behind the label, the dependent instruction -- twice
+                f32x4 acc = zero, e = zero;
+                float m0 = 0.f, m1 = 0.f;
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %5, 0\n\t"
+                             "v_mov_b32 %2, 0\n\tv_mov_b32 %3, 0\n\t"
+                             "s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 1f\n\t"
+                             "v_mfma_f32_16x16x32_bf16 %1, %6, %5, 0\n"
+                             "1:\n\t"
+                             ".rept %10\n\ts_nop 0\n\t.endr\n\t"
+                             "v_mfma_f32_16x16x32_bf16 %0, %6, %7, %0\n\t"
+                             "s_cmp_eq_u32 0, 0\n\ts_cbranch_scc1 2f\n\t"
+                             "v_mfma_f32_16x16x32_bf16 %1, %8, %7, %1\n"
+                             "2:\n\t"
+                             ".rept %10\n\ts_nop 0\n\t.endr\n\t"
+                             "v_mfma_f32_16x16x32_bf16 %0, %8, %9, %0\n\t"
+                             "s_nop 7\n\ts_nop 7\n\ts_nop 7"
+                             : "+v"(acc), "+v"(e), "+v"(m0), "+v"(m1)
+                             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "n"(NOPS < 0 ? 0 : NOPS)
+                             : "scc");
+                c = acc;
+                junk += e[0] + m0 + m1;
+            } else if (OVERLAP) {
                 f32x4 acc = zero;
                 u32x4 b1 = b[1];
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, 0\n\ts_nop 0\n\t"
@@ -109,5 +132,21 @@ int main() {
                alone ? "every wave runs the chain" : "one wave runs the chain beside eleven busy waves",
                overlap ? "third destination = second B operand" : "uniform branches between the three as in the tail", bad, n);
     }
+    // the hand-written sequence: how many wait states behind the label does the dependent instruction need?
+    auto run = [&](auto kern, int nops) {
+        hipMemset(d_bad, 0, 8);
+        const int iters = 20000, grid = 256;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 0, 0, iters, 13, d_bad, d_sink);
+        hipDeviceSynchronize();
+        unsigned bad = 0;
+        hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+        printf("taken branch between the links, %d wait state(s) behind the label, one wave at priority 3 beside eleven busy waves: "
+               "%u of %.3g values differ\n", nops, bad, 256.0 * 20000 * 256.0);
+    };
+    run(probe<false, false, 0>, 0);
+    run(probe<false, false, 1>, 1);
+    run(probe<false, false, 2>, 2);
+    run(probe<false, false, 4>, 4);
+    run(probe<false, false, 8>, 8);
     return 0;
 }
